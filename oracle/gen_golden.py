@@ -1,0 +1,223 @@
+"""Golden-vector generator: runs the REFERENCE itself (build container only).
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+Imports the unmodified reference sources from /root/reference by path
+(models/vlmo/vlmo.py, dall_e/encoder.py, models/modeling_discrete_vae.py),
+loads the key-addressed synthetic weights of oracle/synth.py into the
+reference modules and records their CPU fp32 outputs and gradients.  The
+reference cannot travel to the GPU box; only the .npz data produced here and
+this script are committed.
+
+timm is a third-party dependency of the reference that is neither vendored in
+/root/reference nor installed here (misc/requirements.txt lists it unpinned).
+The five symbols the reference imports from it are provided by a stand-in that
+restates their published semantics: Mlp, PatchEmbed,
+DropPath, trunc_normal_, ModelEmaV2.  Parity of those five is therefore
+"unpinned by reference tests" and anchored on the reference's call sites
+(vlmo.py:141-157, 231-237, 132-133).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   'tests', 'golden')
+
+
+def _install_timm_standin():
+    import transformers  # noqa: F401  (must be imported before the stand-in exists)
+    from transformers.models.bert import modeling_bert  # noqa: F401
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, out_features=None,
+                     act_layer=nn.GELU, drop=0.):
+            super().__init__()
+            out_features = out_features or in_features
+            hidden_features = hidden_features or in_features
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.drop1 = nn.Dropout(drop)
+            self.fc2 = nn.Linear(hidden_features, out_features)
+            self.drop2 = nn.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768,
+                     norm_layer=None):
+            super().__init__()
+            self.img_size = (img_size, img_size)
+            self.patch_size = (patch_size, patch_size)
+            self.grid_size = (img_size // patch_size, img_size // patch_size)
+            self.num_patches = self.grid_size[0] * self.grid_size[1]
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size,
+                                  stride=patch_size)
+            self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+        def forward(self, x):
+            return self.norm(self.proj(x).flatten(2).transpose(1, 2))
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0. or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+            return x * x.new_empty(shape).bernoulli_(keep).div_(keep)
+
+    def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
+        return nn.init.trunc_normal_(tensor, mean, std, a, b)
+
+    class ModelEmaV2(nn.Module):
+        def __init__(self, model, decay=0.9999, device=None):
+            super().__init__()
+            raise NotImplementedError('EMA branch is out of scope')
+
+    timm = types.ModuleType('timm')
+    models = types.ModuleType('timm.models')
+    layers = types.ModuleType('timm.models.layers')
+    utils = types.ModuleType('timm.utils')
+    layers.Mlp, layers.PatchEmbed = Mlp, PatchEmbed
+    layers.DropPath, layers.trunc_normal_ = DropPath, trunc_normal_
+    utils.ModelEmaV2 = ModelEmaV2
+    timm.models, timm.utils, models.layers = models, utils, layers
+    sys.modules.update({'timm': timm, 'timm.models': models,
+                        'timm.models.layers': layers, 'timm.utils': utils})
+
+
+def _ref_vlmo(mc):
+    from functools import partial
+    from models.vlmo.vlmo import VLMO, LayerNorm
+    norm_layer = partial(LayerNorm, eps=1e-12, export=True)  # vlmo_module.py:21-23
+    m = VLMO(img_size=mc.img_size, patch_size=mc.patch_size, in_chans=mc.in_chans,
+             num_classes=mc.num_classes, embed_dim=mc.embed_dim, depth=mc.depth,
+             num_heads=mc.num_heads, mlp_ratio=int(mc.mlp_ratio),
+             qkv_bias=mc.qkv_bias, qk_scale=None, drop_rate=0.0,
+             attn_drop_rate=0.0, drop_path_rate=0.0, norm_layer=norm_layer,
+             init_values=mc.init_values, vocab_size=mc.vocab_size,
+             max_text_len=mc.max_text_len, fusion_layer=mc.fusion_layer)
+    return m.eval()
+
+
+def grad_probe(key, shape):
+    """Fixed pseudo-random projection vector for gradient fingerprints."""
+    from oracle.synth import _normal
+    return _normal(777, 'probe:' + key, shape)
+
+
+def out_weights(mode, shape):
+    from oracle.synth import _normal
+    return _normal(4242, 'R:' + mode, shape)
+
+
+def run_backbone_case(name, preset, B, with_grads=True, full_out=True, seed=0):
+    from oracle import synth
+    cfg = synth.make_config(preset)
+    mc = cfg.model
+    all_experts = [('v', 'l', 'vl')] * mc.depth
+    sd = synth.synth_backbone_state_dict(mc, seed, all_experts)
+    model = _ref_vlmo(mc)
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    batch = synth.synth_batch(mc, B, seed=1234)
+    P = synth.num_img_tokens(mc)
+    img_mask = torch.ones(B, P, dtype=torch.int64)
+    rec = {}
+    modes = {
+        'vl': dict(img=batch['image'], txt=batch['text_ids'], img_attn_masks=img_mask,
+                   txt_attn_masks=batch['text_mask']),
+        'v': dict(img=batch['image'], img_attn_masks=img_mask),
+        'l': dict(txt=batch['text_ids'], txt_attn_masks=batch['text_mask']),
+        'vl_mim': dict(img=batch['image'], txt=batch['text_ids'], img_attn_masks=img_mask,
+                       txt_attn_masks=batch['text_mask'],
+                       bool_masked_pos=batch['image_bool_masked_pos'].flatten(1)),
+    }
+    for mode, kw in modes.items():
+        model.zero_grad(set_to_none=True)
+        x, m = model.forward_features(**kw)
+        xd = x.detach()
+        if full_out:
+            rec[f'{mode}.out'] = xd.numpy().astype(np.float32)
+        else:
+            rec[f'{mode}.out_cls'] = xd[:, 0].numpy().astype(np.float32)
+            rec[f'{mode}.out_rows'] = xd[:, ::17].numpy().astype(np.float32)
+        rec[f'{mode}.out_sum'] = np.float64(xd.double().sum().item())
+        rec[f'{mode}.out_abs'] = np.float64(xd.double().abs().sum().item())
+        rec[f'{mode}.mask'] = m.numpy()
+        rec[f'{mode}.pooled'] = model.pooler(xd).detach().numpy()
+        if with_grads and mode in ('vl', 'v', 'l', 'vl_mim'):
+            R = out_weights(mode, x.shape)
+            (x * R).sum().backward()
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                g = p.grad.detach()
+                rec[f'{mode}.grad_norm.{k}'] = np.float64(g.double().norm().item())
+                rec[f'{mode}.grad_probe.{k}'] = np.float64(
+                    (g.double() * grad_probe(k, g.shape).double()).sum().item())
+                if g.numel() <= 16384:
+                    rec[f'{mode}.grad.{k}'] = g.numpy().astype(np.float32)
+    # forward_interval (objectives.py:556-567 'fusion' MIM head position)
+    xi = model.forward_interval(x=batch['image'], attn_masks=None, route='v', need_embed=True,
+                                bool_masked_pos=batch['image_bool_masked_pos'].flatten(1),
+                                in_layer=0, out_layer=mc.fusion_layer, need_norm=True)
+    rec['interval_v.out'] = xi.detach().numpy().astype(np.float32) if full_out else \
+        xi.detach()[:, ::17].numpy().astype(np.float32)
+    rec['meta.B'] = np.int64(B)
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **rec)
+    print(f'wrote {name}.npz with {len(rec)} arrays')
+
+
+def run_dvae_case(name, B, res, seed=0, full_logits=True, **enc_kw):
+    from oracle import synth
+    from dall_e.encoder import Encoder
+    from models.modeling_discrete_vae import Dalle_VAE
+    enc = Encoder(**enc_kw).eval()
+    sd = synth.synth_dvae_state_dict(seed, **enc_kw)
+    r = enc.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    vae = Dalle_VAE(res)            # modeling_discrete_vae.py:224-236 without the pickles
+    vae.encoder = enc
+    g = torch.Generator().manual_seed(99)
+    x = 0.8 * torch.rand(B, 3, res, res, generator=g) + 0.1
+    with torch.no_grad():
+        logits = enc(x)
+        ids = vae.get_codebook_indices(x)
+    top2 = logits.topk(2, dim=1).values
+    rec = {'ids': ids.numpy(), 'top2_gap': (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32),
+           'logits_sum': np.float64(logits.double().sum().item()),
+           'logits_abs': np.float64(logits.double().abs().sum().item()),
+           'logits_max': logits.amax(dim=1).numpy().astype(np.float32)}
+    if full_logits:
+        rec['logits'] = logits.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **rec)
+    print(f'wrote {name}.npz')
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, REF)
+    _install_timm_standin()
+    run_backbone_case('backbone_mini', 'mini', B=3)
+    run_backbone_case('backbone_small', 'small', B=2)
+    run_backbone_case('backbone_debug', 'debug', B=2)
+    run_backbone_case('backbone_base_b2', 'base', B=2, full_out=False)
+    run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512)
+    run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,153 @@
+"""Plain-PyTorch fp32 restatement of the VLMO backbone (TEST INFRASTRUCTURE).
+
+Functional: every function takes the backbone state dict ``sd`` (keys as in
+the reference) so that autograd on ``sd`` tensors with
+``requires_grad`` gives reference gradients.  Eval-mode semantics (dropout and
+drop-path are identities), i.e. the configuration the parity tests pin.
+
+Follows, line by line:
+  * LayerNorm eps=1e-12           models/vlmo/vlmo_module.py:21-23, vlmo.py:26-36
+  * Attention.forward             models/vlmo/vlmo.py:68-98
+  * Block.forward                 models/vlmo/vlmo.py:187-197
+  * timm Mlp (fc1, GELU-erf, fc2) models/vlmo/vlmo.py:141-157 (third party)
+  * VLMO.embed_img / embed_txt    models/vlmo/vlmo.py:298-324
+  * transformers BertEmbeddings   word + type[0] + pos[0:T] -> LN(1e-12)
+  * VLMO.forward_features         models/vlmo/vlmo.py:357-414
+  * VLMO.forward_interval         models/vlmo/vlmo.py:326-355
+  * BertPooler                    tanh(W x[:,0] + b), vlmo_module.py:379
+"""
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-12
+
+
+def layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
+
+
+def attention(sd, p, x, mask, num_heads):
+    """vlmo.py:68-98.  Returns (out, attn_probs)."""
+    B, N, C = x.shape
+    dh = C // num_heads
+    qkv_bias = torch.cat((sd[p + 'q_bias'],
+                          torch.zeros_like(sd[p + 'v_bias']),
+                          sd[p + 'v_bias']))
+    qkv = F.linear(x, sd[p + 'qkv.weight'], qkv_bias)
+    qkv = qkv.reshape(B, N, 3, num_heads, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * dh ** -0.5
+    if mask is not None:
+        attn = attn.masked_fill(~mask.bool()[:, None, None, :], float('-inf'))
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    x = F.linear(x, sd[p + 'proj.weight'], sd[p + 'proj.bias'])
+    return x, attn
+
+
+def mlp(sd, p, x):
+    h = F.gelu(F.linear(x, sd[p + 'fc1.weight'], sd[p + 'fc1.bias']))
+    return F.linear(h, sd[p + 'fc2.weight'], sd[p + 'fc2.bias'])
+
+
+def block(sd, i, x, mask, route, num_heads):
+    """vlmo.py:187-197 (gamma branch; eval-mode DropPath = identity)."""
+    p = f'blocks.{i}.'
+    a, _ = attention(sd, p + 'attn.',
+                     layer_norm(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias']),
+                     mask, num_heads)
+    x = x + sd[p + 'gamma_1'] * a
+    m = mlp(sd, p + f'mlp.{route}.',
+            layer_norm(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias']))
+    x = x + sd[p + 'gamma_2'] * m
+    return x
+
+
+def embed_img(sd, mc, img, bool_masked_pos=None, img_token_type_idx=1):
+    """vlmo.py:298-319 with timm PatchEmbed = conv(k=s=patch).flatten(2).T."""
+    x = F.conv2d(img, sd['patch_embed.proj.weight'], sd['patch_embed.proj.bias'],
+                 stride=mc.patch_size)
+    x = x.flatten(2).transpose(1, 2)
+    B, S, _ = x.shape
+    if bool_masked_pos is not None:
+        w = bool_masked_pos.reshape(B, -1).unsqueeze(-1).type_as(x)
+        x = x * (1 - w) + sd['img_mask_token'].expand(B, S, -1) * w
+    x = torch.cat((sd['img_cls_token'].expand(B, -1, -1), x), dim=1)
+    x = x + sd['pos_embed']
+    x = x + sd['token_type_embeddings.weight'][img_token_type_idx]
+    return x
+
+
+def embed_txt(sd, mc, ids):
+    """vlmo.py:321-324; BertEmbeddings with token_type_ids = 0, positions 0..T-1."""
+    T = ids.shape[1]
+    # BertEmbeddings.word_embeddings has padding_idx=0: row 0 is looked up like any
+    # other row in forward but receives no gradient.
+    e = F.embedding(ids, sd['txt_embeddings.word_embeddings.weight'], padding_idx=0)
+    e = e + sd['txt_embeddings.token_type_embeddings.weight'][0]
+    e = e + sd['txt_embeddings.position_embeddings.weight'][:T]
+    e = layer_norm(e, sd['txt_embeddings.LayerNorm.weight'],
+                   sd['txt_embeddings.LayerNorm.bias'])
+    return e + sd['token_type_embeddings.weight'][0]
+
+
+def forward_features(sd, mc, img=None, txt=None, img_attn_masks=None,
+                     txt_attn_masks=None, bool_masked_pos=None,
+                     fusion_layer=None, img_token_type_idx=1,
+                     return_intermediates=False):
+    """vlmo.py:357-414.  Returns (x, mask) (+ per-block outputs if asked)."""
+    h, L = mc.num_heads, mc.depth
+    inter = []
+    final = lambda x: layer_norm(x, sd['norm.weight'], sd['norm.bias'])
+    if txt is None:
+        x = embed_img(sd, mc, img, bool_masked_pos, img_token_type_idx)
+        for i in range(L):
+            x = block(sd, i, x, img_attn_masks, 'v', h)
+            inter.append(x)
+        out = (final(x), img_attn_masks)
+        return out + (inter,) if return_intermediates else out
+    if img is None:
+        x = embed_txt(sd, mc, txt)
+        for i in range(L):
+            x = block(sd, i, x, txt_attn_masks, 'l', h)
+            inter.append(x)
+        out = (final(x), txt_attn_masks)
+        return out + (inter,) if return_intermediates else out
+    xi = embed_img(sd, mc, img, bool_masked_pos, img_token_type_idx)
+    xt = embed_txt(sd, mc, txt)
+    Fl = fusion_layer or mc.fusion_layer
+    assert 0 <= Fl <= L
+    for i in range(Fl):
+        xi = block(sd, i, xi, img_attn_masks, 'v', h)
+        xt = block(sd, i, xt, txt_attn_masks, 'l', h)
+        inter.append(torch.cat([xt, xi], dim=1))
+    x = torch.cat([xt, xi], dim=1)          # text first: vlmo.py:406
+    m = torch.cat([txt_attn_masks, img_attn_masks], dim=1)
+    for i in range(Fl, L):
+        x = block(sd, i, x, m, 'vl', h)
+        inter.append(x)
+    out = (final(x), m)
+    return out + (inter,) if return_intermediates else out
+
+
+def forward_interval(sd, mc, x, attn_masks, route, need_embed=False,
+                     bool_masked_pos=None, in_layer=None, out_layer=None,
+                     img_token_type_idx=1, need_norm=False):
+    """vlmo.py:326-355."""
+    assert route in ['v', 'l', 'vl']
+    if need_embed:
+        if route == 'v':
+            if attn_masks is None:
+                attn_masks = torch.ones(x.shape[0], (mc.img_size // mc.patch_size) ** 2 + 1,
+                                        dtype=torch.int64)
+            x = embed_img(sd, mc, x, bool_masked_pos, img_token_type_idx)
+        elif route == 'l':
+            x = embed_txt(sd, mc, x)
+    for i in list(range(mc.depth))[in_layer:out_layer]:
+        x = block(sd, i, x, attn_masks, route, mc.num_heads)
+    return layer_norm(x, sd['norm.weight'], sd['norm.bias']) if need_norm else x
+
+
+def pooler(sd, x):
+    return torch.tanh(F.linear(x[:, 0], sd['pooler.dense.weight'],
+                               sd['pooler.dense.bias']))
