@@ -1,0 +1,482 @@
+// Fused multi-head softmax attention for VLMo on gfx950 (head_dim 64).
+// Reference: Attention.forward, vlmo.py:79-95:
+//   attn = softmax((q k^T) * dh^-0.5 + keymask(-inf)) ; dropout ; ctx = attn v
+// VLMo sequences are short (64 / 197 / 261 tokens), so a whole head's K and V
+// sit in LDS (<= 36 KB each) and a wavefront keeps a complete 32-query x N-key
+// score tile in registers: exact softmax, no online rescaling, no N x N tensor
+// in HBM (the reference materialises [B,h,N,N] several times).
+//
+// Orientation: scores are computed TRANSPOSED, S^T[key][query] = K . Q^T, so a
+// lane owns one query column (softmax reductions are in-register + one
+// cross-half shuffle) and the fp32 accumulator tile is directly the B operand
+// of the next MFMA (O^T = V^T . P^T) after a bf16 pack; V^T fragments come from
+// ds_read_b64_tr_b16.  All four operand images use one dual-use swizzle that
+// is bank-conflict free for row reads and transposed reads (tests/ldssim.py).
+//
+// Packed rows: sequence s = rows [rowA,rowA+lenA) ++ [rowB,rowB+lenB) of the
+// [M, 3d] qkv matrix, so text+image fusion needs no concatenated copy.
+#include "common.h"
+#include "vlmo_hip.h"
+
+namespace {
+
+struct AttnArgs {
+    const bf16* qkv;
+    const bf16* ctx;      // bwd: forward output
+    const bf16* dctx;     // bwd: grad of ctx
+    bf16* out;            // fwd: ctx ; bwd: dqkv
+    float* lse;
+    const int32_t* seg;
+    const int32_t* keymask;
+    int lse_stride, heads, d;
+    float scale, scale_log2e;
+    uint32_t drop_thresh;
+    float inv_keep;
+    uint64_t seed;
+};
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+__device__ __forceinline__ int att_off(int row, int ch) {
+    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+// stage rows [0, NPAD) x 64 columns starting at column `col0` of qkv-like matrix
+// into a dual-use image by LDS-DMA (one wave-instruction = 8 rows = 1 KiB)
+template <int NWAVES>
+__device__ __forceinline__ void stage_image(const bf16* base, int ld, int col0, const int* rowidx, char* img, int ninstr,
+                                            int wave, int lane) {
+    const int chhi = lane >> 5, rowlo = (lane >> 2) & 7, pc = lane & 3;
+    for (int ii = wave; ii < ninstr; ii += NWAVES) {
+        const int row = ii * 8 + rowlo;
+        const int ch = chhi * 4 + (pc ^ ((row >> 2) & 3));
+        glds16(base + (size_t)rowidx[row] * ld + col0 + ch * 8, img + ii * 1024);
+    }
+}
+
+__device__ __forceinline__ uint64_t att_drop_bits(uint64_t seed, int bh, int q, int key) {
+    return drop_bits4(seed, ((uint64_t)bh * 4096 + q) * 1024 + (key >> 2));
+}
+
+// B/A operand by row read: rows row_base + (lane&31), features 16*ks + 8*(lane>>5) ..+7
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row_base, int ks, int lane) {
+    return *(const bf16x8*)(img + att_off(row_base + (lane & 31), 2 * ks + (lane >> 5)));
+}
+// A operand by transposed read: operand rows = features cb + (lane&31), k = image rows in
+// accumulator order rb + 8*(j>>2) + 4*(lane>>5) + (j&3)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int rb, int cb, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = lane >> 5;
+    const int col = cb + 16 * (g & 1) + 4 * pp;
+    const int r0 = rb + 4 * h + q;
+    const bf16x4 lo = lds_tr4<bf16>(img + att_off(r0, col >> 3) + (col & 7) * 2);
+    const bf16x4 hi = lds_tr4<bf16>(img + att_off(r0 + 8, col >> 3) + (col & 7) * 2);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ void setup_rows(const int32_t* seg, int sidx, const int32_t* keymask, int npad, int* rowidx,
+                                           float* kbias, int& N) {
+    const int rowA = seg[4 * sidx + 0], lenA = seg[4 * sidx + 1], rowB = seg[4 * sidx + 2], lenB = seg[4 * sidx + 3];
+    N = lenA + lenB;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int tok = min(i, N - 1);
+        const int row = tok < lenA ? rowA + tok : rowB + (tok - lenA);
+        rowidx[i] = row;
+        const bool ok = (i < N) && (!keymask || keymask[row] != 0);
+        kbias[i] = ok ? 0.f : -INFINITY;
+    }
+}
+
+// Keys are swept in chunks of CK*32 = 128 with an exact running max (the chunk's
+// scores live in 64 accumulator registers; O is rescaled at most once per chunk).
+#define ATT_CK 4
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, const int NPAD) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kimg = smem;
+    char* Vimg = smem + NPAD * 128;
+    float* kbias = (float*)(smem + 2 * NPAD * 128);
+    int* rowidx = (int*)(kbias + NPAD);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.x, sidx = bh / a.heads, hd = bh % a.heads;
+    const int ld = 3 * a.d;
+    int N;
+    setup_rows(a.seg, sidx, a.keymask, NPAD, rowidx, kbias, N);
+    __syncthreads();
+    const int nq = (N + 31) >> 5;
+    stage_image<4>(a.qkv, ld, a.d + hd * 64, rowidx, Kimg, nq * 4, wave, lane);
+    stage_image<4>(a.qkv, ld, 2 * a.d + hd * 64, rowidx, Vimg, nq * 4, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int l31 = lane & 31, h = lane >> 5;
+    for (int qt = wave; qt < nq; qt += 4) {
+        const int qi = qt * 32 + l31;
+        const int qrow = rowidx[qi];
+        const bf16* qp = a.qkv + (size_t)qrow * ld + hd * 64 + 8 * h;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 O[2] = {zero16(), zero16()};
+        for (int c0 = 0; c0 < nq; c0 += ATT_CK) {
+            f32x16 S[ATT_CK];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < ATT_CK; ++c) {
+                S[c] = zero16();
+                const int kt = c0 + c;
+                if (kt < nq) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) S[c] = Elem<bf16>::mfma(row_frag(Kimg, kt * 32, s, lane), qf[s], S[c]);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 kb = *(const f32x4*)(kbias + kt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = S[c][4 * g4 + e] * a.scale_log2e + kb[e];
+                            S[c][4 * g4 + e] = t;
+                            mx = fmaxf(mx, t);
+                        }
+                    }
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const bool dead = (m_new == -INFINITY);            // every key so far is masked
+            const float alpha = dead ? 1.f : exp2f(m_run - m_new);
+            float lsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < ATT_CK; ++c) {
+                if (c0 + c < nq) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = dead ? 0.f : exp2f(S[c][i] - m_new);
+                        S[c][i] = p;
+                        lsum += p;
+                    }
+                }
+            }
+            lsum += __shfl_xor(lsum, 32, 64);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+#pragma unroll
+            for (int c = 0; c < ATT_CK; ++c) {
+                const int kt = c0 + c;
+                if (kt < nq) {
+                    if (a.drop_thresh) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const uint64_t bits = att_drop_bits(a.seed, bh, qi, kt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (!drop_keep(bits, e, a.drop_thresh)) S[c][4 * g4 + e] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 pf;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[j] = (bf16)S[c][8 * s2 + j];
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            O[dt] = Elem<bf16>::mfma(tr_frag(Vimg, kt * 32 + 16 * s2, dt * 32, lane), pf, O[dt]);
+                    }
+                }
+            }
+        }
+        if (qi < N) {
+            const float inv = a.inv_keep / l_run;
+            bf16* op = a.out + (size_t)qrow * a.d + hd * 64 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x4 o = {(bf16)(O[dt][4 * g4 + 0] * inv), (bf16)(O[dt][4 * g4 + 1] * inv),
+                                (bf16)(O[dt][4 * g4 + 2] * inv), (bf16)(O[dt][4 * g4 + 3] * inv)};
+                    *(bf16x4*)(op + dt * 32 + 8 * g4) = o;
+                }
+            if (h == 0 && a.lse) a.lse[(size_t)bh * a.lse_stride + qi] = (m_run + log2f(l_run)) * LN2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+// Two phases in one launch, sharing the Q/K/V/dO LDS images:
+//   phase 1: a wavefront owns 32 queries, sweeps key tiles  -> dQ   (no reduction across waves)
+//   phase 2: a wavefront owns 32 keys,    sweeps query tiles -> dK, dV
+// P is recomputed from the forward's log-sum-exp; delta = rowsum(dO * O).
+__global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, const int NPAD) {
+    const int IMG = NPAD * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qimg = smem;
+    char* Kimg = smem + IMG;
+    char* Vimg = smem + 2 * IMG;
+    char* Dimg = smem + 3 * IMG;
+    float* kbias = (float*)(smem + 4 * IMG);
+    float* lseq = kbias + NPAD;    // log2-domain LSE per query (+inf on padded queries)
+    float* delta = lseq + NPAD;
+    int* rowidx = (int*)(delta + NPAD);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.x, sidx = bh / a.heads, hd = bh % a.heads;
+    const int ld = 3 * a.d;
+    int N;
+    setup_rows(a.seg, sidx, a.keymask, NPAD, rowidx, kbias, N);
+    __syncthreads();
+    const int nq = (N + 31) >> 5;   // query tiles == key tiles (self-attention)
+    stage_image<8>(a.qkv, ld, hd * 64, rowidx, Qimg, nq * 4, wave, lane);
+    stage_image<8>(a.qkv, ld, a.d + hd * 64, rowidx, Kimg, nq * 4, wave, lane);
+    stage_image<8>(a.qkv, ld, 2 * a.d + hd * 64, rowidx, Vimg, nq * 4, wave, lane);
+    stage_image<8>(a.dctx, a.d, hd * 64, rowidx, Dimg, nq * 4, wave, lane);
+    for (int i = threadIdx.x; i < NPAD; i += 512) {
+        float dl = 0.f, lq = INFINITY;
+        if (i < N) {
+            const size_t o = (size_t)rowidx[i] * a.d + hd * 64;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 x = *(const bf16x8*)(a.ctx + o + 8 * c);
+                const bf16x8 y = *(const bf16x8*)(a.dctx + o + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)x[j] * (float)y[j];
+            }
+            lq = a.lse[(size_t)bh * a.lse_stride + i] * LOG2E;
+        }
+        delta[i] = dl;
+        lseq[i] = lq;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // ---- phase 1: dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
+    for (int qt = wave; qt < nq; qt += 8) {
+        const int qi = qt * 32 + l31;
+        bf16x8 qf[4], df[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = row_frag(Qimg, qt * 32, s, lane);
+            df[s] = row_frag(Dimg, qt * 32, s, lane);
+        }
+        const float lq = lseq[qi], dl = delta[qi];
+        f32x16 dQ[2] = {zero16(), zero16()};
+        for (int kt = 0; kt < nq; ++kt) {
+            {
+                f32x16 S = zero16(), dP = zero16();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    S = Elem<bf16>::mfma(row_frag(Kimg, kt * 32, s, lane), qf[s], S);
+                    dP = Elem<bf16>::mfma(row_frag(Vimg, kt * 32, s, lane), df[s], dP);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 kb = *(const f32x4*)(kbias + kt * 32 + 8 * g4 + 4 * h);
+                    uint64_t bits = 0;
+                    if (a.drop_thresh) bits = att_drop_bits(a.seed, bh, qi, kt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g4 + e;
+                        const float p = exp2f(S[i] * a.scale_log2e + kb[e] - lq);
+                        float dp = dP[i];
+                        if (a.drop_thresh) dp = drop_keep(bits, e, a.drop_thresh) ? dp * a.inv_keep : 0.f;
+                        S[i] = p * (dp - dl) * a.scale;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 sf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sf[j] = (bf16)S[8 * s2 + j];
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        dQ[dt] = Elem<bf16>::mfma(tr_frag(Kimg, kt * 32 + 16 * s2, dt * 32, lane), sf, dQ[dt]);
+                }
+            }
+        }
+        if (qi < N) {
+            bf16* op = a.out + (size_t)rowidx[qi] * ld + hd * 64 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x4 o = {(bf16)dQ[dt][4 * g4 + 0], (bf16)dQ[dt][4 * g4 + 1], (bf16)dQ[dt][4 * g4 + 2],
+                                (bf16)dQ[dt][4 * g4 + 3]};
+                    *(bf16x4*)(op + dt * 32 + 8 * g4) = o;
+                }
+        }
+    }
+
+    // ---- phase 2: dV^T[d][k] = sum_q dO^T[d][q] Pd[q][k] ; dK^T[d][k] = sum_q Q^T[d][q] dS[q][k]
+    for (int kt = wave; kt < nq; kt += 8) {
+        const int ki = kt * 32 + l31;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = row_frag(Kimg, kt * 32, s, lane);
+            vf[s] = row_frag(Vimg, kt * 32, s, lane);
+        }
+        const float kb = kbias[ki];
+        f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};
+        for (int qt = 0; qt < nq; ++qt) {
+            {
+                f32x16 S = zero16(), dP = zero16();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    S = Elem<bf16>::mfma(row_frag(Qimg, qt * 32, s, lane), kf[s], S);
+                    dP = Elem<bf16>::mfma(row_frag(Dimg, qt * 32, s, lane), vf[s], dP);
+                }
+                f32x16 Pd;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int q0 = qt * 32 + 8 * g4 + 4 * h;
+                    const f32x4 lq = *(const f32x4*)(lseq + q0);
+                    const f32x4 dl = *(const f32x4*)(delta + q0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g4 + e;
+                        const float p = exp2f(S[i] * a.scale_log2e + kb - lq[e]);
+                        float dp = dP[i], pd = p;
+                        if (a.drop_thresh) {
+                            const uint64_t bits = att_drop_bits(a.seed, bh, q0 + e, ki);
+                            const bool keep = drop_keep(bits, ki & 3, a.drop_thresh);
+                            dp = keep ? dp * a.inv_keep : 0.f;
+                            pd = keep ? p * a.inv_keep : 0.f;
+                        }
+                        Pd[i] = pd;
+                        S[i] = p * (dp - dl[e]) * a.scale;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf, sf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        pf[j] = (bf16)Pd[8 * s2 + j];
+                        sf[j] = (bf16)S[8 * s2 + j];
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dV[dt] = Elem<bf16>::mfma(tr_frag(Dimg, qt * 32 + 16 * s2, dt * 32, lane), pf, dV[dt]);
+                        dK[dt] = Elem<bf16>::mfma(tr_frag(Qimg, qt * 32 + 16 * s2, dt * 32, lane), sf, dK[dt]);
+                    }
+                }
+            }
+        }
+        if (ki < N) {
+            bf16* op = a.out + (size_t)rowidx[ki] * ld + hd * 64 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x4 ok = {(bf16)dK[dt][4 * g4 + 0], (bf16)dK[dt][4 * g4 + 1], (bf16)dK[dt][4 * g4 + 2],
+                                 (bf16)dK[dt][4 * g4 + 3]};
+                    bf16x4 ov = {(bf16)dV[dt][4 * g4 + 0], (bf16)dV[dt][4 * g4 + 1], (bf16)dV[dt][4 * g4 + 2],
+                                 (bf16)dV[dt][4 * g4 + 3]};
+                    *(bf16x4*)(op + a.d + dt * 32 + 8 * g4) = ok;
+                    *(bf16x4*)(op + 2 * a.d + dt * 32 + 8 * g4) = ov;
+                }
+        }
+    }
+}
+
+int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
+    const int LDS = nt * 32 * 256 + nt * 32 * 8;
+    static int max_set = 65536;
+    if (LDS > max_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        max_set = LDS;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblocks), dim3(256), LDS, st, a, nt * 32);
+    return 0;
+}
+int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
+    const int LDS = nt * 32 * 512 + nt * 32 * 16;
+    static int max_set = 65536;
+    if (LDS > max_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        max_set = LDS;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblocks), dim3(512), LDS, st, a, nt * 32);
+    return 0;
+}
+
+int check_common(const char* fn, const void* qkv, const int32_t* seg, int num_seq, int heads, int d, int max_len,
+                 int cap) {
+    VLMO_CHECK_ARG(qkv && seg, "%s: null pointer", fn);
+    VLMO_CHECK_ARG(num_seq > 0 && heads > 0, "%s: empty problem", fn);
+    VLMO_CHECK_ARG(d == heads * 64, "%s: head_dim must be 64 (d=%d, heads=%d)", fn, d, heads);
+    VLMO_CHECK_ARG(max_len > 0 && max_len <= cap, "%s: sequence length %d exceeds this build's limit %d", fn, max_len, cap);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, const int32_t* keymask, void* ctx,
+                             float* lse, int lse_stride, int heads, int d, int max_len, float scale,
+                             uint32_t drop_thresh, float inv_keep, uint64_t seed, hipStream_t stream) {
+    if (int rc = check_common("vlmo_attn_fwd", qkv, seg, num_seq, heads, d, max_len, 576)) return rc;
+    VLMO_CHECK_ARG(ctx, "vlmo_attn_fwd: null ctx");
+    VLMO_CHECK_ARG(!lse || lse_stride >= max_len, "vlmo_attn_fwd: lse_stride too small");
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv;
+    a.out = (bf16*)ctx;
+    a.lse = lse;
+    a.seg = seg;
+    a.keymask = keymask;
+    a.lse_stride = lse_stride;
+    a.heads = heads;
+    a.d = d;
+    a.scale = scale;
+    a.scale_log2e = scale * LOG2E;
+    a.drop_thresh = drop_thresh;
+    a.inv_keep = drop_thresh ? inv_keep : 1.f;
+    a.seed = seed;
+    const int nt = (max_len + 31) / 32, nb = num_seq * heads;
+    launch_fwd(a, nt, nb, stream);
+    VLMO_CHECK_LAUNCH("vlmo_attn_fwd");
+    return 0;
+}
+
+extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, int lse_stride,
+                             const int32_t* seg, int num_seq, const int32_t* keymask, void* dqkv, int heads, int d,
+                             int max_len, float scale, uint32_t drop_thresh, float inv_keep, uint64_t seed,
+                             hipStream_t stream) {
+    if (int rc = check_common("vlmo_attn_bwd", qkv, seg, num_seq, heads, d, max_len, 288)) return rc;
+    VLMO_CHECK_ARG(ctx && dctx && lse && dqkv, "vlmo_attn_bwd: null pointer");
+    VLMO_CHECK_ARG(lse_stride >= max_len, "vlmo_attn_bwd: lse_stride too small");
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv;
+    a.ctx = (const bf16*)ctx;
+    a.dctx = (const bf16*)dctx;
+    a.out = (bf16*)dqkv;
+    a.lse = (float*)lse;
+    a.seg = seg;
+    a.keymask = keymask;
+    a.lse_stride = lse_stride;
+    a.heads = heads;
+    a.d = d;
+    a.scale = scale;
+    a.scale_log2e = scale * LOG2E;
+    a.drop_thresh = drop_thresh;
+    a.inv_keep = drop_thresh ? inv_keep : 1.f;
+    a.seed = seed;
+    const int nt = (max_len + 31) / 32, nb = num_seq * heads;
+    launch_bwd(a, nt, nb, stream);
+    VLMO_CHECK_LAUNCH("vlmo_attn_bwd");
+    return 0;
+}

@@ -1,0 +1,110 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) VLMo kernels.
+// gfx950 only: 64-wide wavefronts, MFMA 32x32x16, LDS-DMA (global_load_lds 16 B),
+// ds_read_b64_tr_b16.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- error plumbing (C-ABI: 0 ok, <0 argument error, >0 hipError_t) -------
+void vlmo_set_error(const char* fmt, ...);
+#define VLMO_CHECK_ARG(cond, ...)                         \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            vlmo_set_error(__VA_ARGS__);                  \
+            return -1;                                    \
+        }                                                 \
+    } while (0)
+#define VLMO_CHECK_LAUNCH(name)                                             \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            vlmo_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                \
+        }                                                                   \
+    } while (0)
+
+// ---- element traits: the transformer runs bf16, the dVAE runs fp16 --------
+template <typename T> struct Elem;
+template <> struct Elem<bf16> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<f16> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// ---- LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane*16 -
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+// transposed LDS read: 4x16 block of 16-bit elements, column-major into lanes
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::v4 lds_tr4(const void* p);
+template <>
+__device__ __forceinline__ bf16x4 lds_tr4<bf16>(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(p));
+}
+template <>
+__device__ __forceinline__ f16x4 lds_tr4<f16>(const void* p) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 hv4;
+    const hv4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hv4*)(p));
+    return __builtin_bit_cast(f16x4, r);
+}
+
+// ---- counter-based RNG for dropout: one 64-bit hash -> four 16-bit lanes ---
+// keep(e) <=> u16(e) >= thresh, thresh = round(p * 65536).  Forward and
+// backward regenerate the same mask from (seed, element-group index).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t drop_bits4(uint64_t seed, uint64_t group_idx) {
+    return mix64(seed + group_idx * 0x9E3779B97F4A7C15ull);
+}
+__device__ __forceinline__ bool drop_keep(uint64_t bits, int j, uint32_t thresh) {
+    return ((uint32_t)(bits >> (16 * j)) & 0xFFFFu) >= thresh;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,421 @@
+// MFMA GEMMs for the VLMo hot path on gfx950.
+//
+//  gemm_nt : C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
+//            forward linears (x . W^T) and, with pre-transposed weights, dgrad.
+//            Reference call sites: vlmo.py:70-80 (qkv), :96 (proj), timm Mlp
+//            fc1/fc2 (vlmo.py:141-157), patch-embed conv as GEMM (vlmo.py:304).
+//  gemm_tn : C[N1,N2] += A[M,N1]^T . B[M,N2] (reduction over rows, split over
+//            the grid's z dimension, fp32 atomics) = wgrad.
+//
+// Structure (per workgroup): BMxBNx64 tile, operands staged global->LDS by
+// LDS-DMA (global_load_lds, 16 B/lane) into a 2-deep ring, XOR-swizzled on the
+// SOURCE address so ds_read_b128 fragment reads are bank-conflict free, one
+// barrier per K-tile, v_mfma_f32_32x32x16 accumulating in fp32, epilogue
+// transposed through wave-private LDS so every global access is a full
+// 128/256-byte row segment with the bias/GELU/dropout/layer-scale/residual
+// math fused in.
+#include "common.h"
+#include "vlmo_hip.h"
+
+namespace {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3, EPI_F32 = 4 };
+
+struct GemmNT {
+    const void* A;
+    const void* B;
+    int M, N, K, lda, ldb;
+    VlmoEpilogue e;
+};
+
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, float a, float b, float c, float d) {
+    bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+    *(bf16x4*)p = v;
+}
+template <> __device__ __forceinline__ void store4<f16>(f16* p, float a, float b, float c, float d) {
+    f16x4 v = {(f16)a, (f16)b, (f16)c, (f16)d};
+    *(f16x4*)p = v;
+}
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <> __device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
+    f16x4 v = *(const f16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// One call = 4 consecutive output columns (gn..gn+3) of row gm.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4 v) {
+    const VlmoEpilogue& e = p.e;
+    if (e.bias) {
+        const f32x4 b = *(const f32x4*)(e.bias + gn);
+        v += b;
+    }
+    const size_t o = (size_t)gm * e.ldo + gn;
+    if constexpr (EPI == EPI_BIAS) {
+        if (e.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_F32) {
+        float* out = (float*)e.out + o;
+        if (e.beta != 0.f) v += e.beta * (*(const f32x4*)out);
+        *(f32x4*)out = v;
+    } else if constexpr (EPI == EPI_BIAS_GELU) {
+        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);   // u (pre-activation)
+        // GELU on the value the backward will see (u rounded to T)
+        f32x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = gelu_erf(v[j]);
+        if (e.drop_thresh) {
+            const uint64_t bits = drop_bits4(e.seed, ((uint64_t)gm * p.N + gn) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = drop_keep(bits, j, e.drop_thresh) ? h[j] * e.inv_keep : 0.f;
+        }
+        store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, h[0], h[1], h[2], h[3]);
+    } else if constexpr (EPI == EPI_RESID) {
+        if (e.drop_thresh) {
+            const uint64_t bits = drop_bits4(e.seed, ((uint64_t)gm * p.N + gn) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
+        }
+        if (e.out2) store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, v[0], v[1], v[2], v[3]);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f};
+        if (e.gamma) g = *(const f32x4*)(e.gamma + gn);
+        const float rs = e.row_scale ? e.row_scale[gm] : 1.f;
+        const f32x4 r = *(const f32x4*)(e.resid + o);
+        *(f32x4*)((float*)e.out + o) = r + g * v * rs;
+    } else if constexpr (EPI == EPI_DGELU) {
+        const f32x4 u = load4<T>((const T*)e.aux + (size_t)gm * e.ld2 + gn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+        if (e.drop_thresh) {
+            const uint64_t bits = drop_bits4(e.seed, ((uint64_t)gm * p.N + gn) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
+        }
+        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+    }
+}
+
+// bijective XCD-chunked remap: workgroups that share an XCD (bid % 8 equal)
+// get a contiguous range of logical tile ids, so the A row-panel re-reads of
+// neighbouring column tiles hit that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
+    typedef typename Elem<T>::v8 v8;
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+    static_assert(NW * 32 * TN * 32 * 4 <= 2 * STAGE, "epilogue LDS must fit in the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+    const T* a_src[NA];
+    const T* b_src[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int gr = min(m0 + r, p.M - 1);
+        a_src[i] = (const T*)p.A + (size_t)gr * p.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int gr = min(n0 + r, p.N - 1);
+        b_src[i] = (const T*)p.B + (size_t)gr * p.ldb + c * 8;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int a_row_off = (wm * (BM / WM) + l31) * 128;
+    const int b_row_off = A_BYTES + (wn * (BN / WN) + l31) * 128;
+
+    const int nk = p.K >> 6;
+    auto stage = [&](int buf, int kt) {
+        char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(a_src[i] + kt * 64, s + (i * NW + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(b_src[i] + kt * 64, s + A_BYTES + (i * NW + wave) * 1024);
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* s = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((2 * ks + h) ^ swz) << 4;
+            v8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const v8*)(s + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const v8*)(s + b_row_off + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: accumulators -> wave-private LDS -> full-row segments ----
+    __syncthreads();
+    constexpr int ROWF = TN * 32;                 // floats per LDS row
+    constexpr int LPR = TN * 8, RPI = 64 / LPR;   // lanes per row, rows per read instr
+    float* ep = (float*)(smem + wave * (32 * ROWF * 4));
+    const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * h) * ROWF + j * 32 + l31] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + rrow;
+            const f32x4 v = *(const f32x4*)(ep + row * ROWF + rcol);
+            const int gm = m0 + wm * (BM / WM) + i * 32 + row;
+            const int gn = n0 + wn * (BN / WN) + rcol;
+            if (gm < p.M && gn < p.N) epilogue4<T, EPI>(p, gm, gn, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------ wgrad ---
+struct GemmTN {
+    const void* A;   // [M, lda], uses columns [0, N1)
+    const void* B;   // [M, ldb], uses columns [0, N2)
+    float* C;        // [N1, ldc] fp32, atomically accumulated
+    int M, N1, N2, lda, ldb, ldc;
+    int kt_per_split;
+    float alpha;
+};
+
+// dual-use 256-byte-row image: chunk swizzle serving the transposed reads
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
+    typedef typename Elem<T>::v8 v8;
+    typedef typename Elem<T>::v4 v4;
+    constexpr int TILE_BYTES = 64 * 256, STAGE = 2 * TILE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N2 + 127) / 128;
+    const int n1_0 = (blockIdx.x / tiles_n) * 128, n2_0 = (blockIdx.x % tiles_n) * 128;
+    const int nk_total = (p.M + 63) >> 6;
+    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int kt1 = min(nk_total, kt0 + p.kt_per_split);
+    if (kt0 >= kt1) return;
+
+    // staging: one wave-instruction = 4 rows x 256 B; 16 instructions per operand tile
+    int a_off[4], b_off[4], srow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ tn_swz(row);
+        srow[i] = row;
+        a_off[i] = min(n1_0 + ch * 8, p.N1 - 8);
+        b_off[i] = min(n2_0 + ch * 8, p.N2 - 8);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr = min(kt * 64 + srow[i], p.M - 1);
+            glds16((const T*)p.A + (size_t)gr * p.lda + a_off[i], s + (i * 4 + wave) * 1024);
+            glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + TILE_BYTES + (i * 4 + wave) * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    // transposed-read addressing (ds_read_b64_tr_b16): lane 4q+p of a 16-lane
+    // group supplies row q, columns 4p..4p+3 of a 4x16 block
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = lane >> 5;
+    const int ncol_a = wm * 64 + 16 * (g & 1) + 4 * pp;   // + tile*32
+    const int ncol_b = wn * 64 + 16 * (g & 1) + 4 * pp;
+
+    stage(0, kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < kt1) stage((kt - kt0 + 1) & 1, kt + 1);
+        const char* s = smem + ((kt - kt0) & 1) * STAGE;
+        const bool tail = (kt * 64 + 64 > p.M);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            v8 af[2], bf[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int m = 16 * ks + 8 * h + 4 * half + q;
+                const int sw = tn_swz(m);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int na = ncol_a + t * 32, nb = ncol_b + t * 32;
+                    const v4 va = lds_tr4<T>(s + m * 256 + (((na >> 3) ^ sw) << 4) + (na & 7) * 2);
+                    const v4 vb = lds_tr4<T>(s + TILE_BYTES + m * 256 + (((nb >> 3) ^ sw) << 4) + (nb & 7) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        af[t][4 * half + e] = va[e];
+                        bf[t][4 * half + e] = vb[e];
+                    }
+                }
+            }
+            if (tail) {
+                // rows >= M were loaded from the clamped last row: zero one operand
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = (kt * 64 + 16 * ks + 8 * h + e) < p.M;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        if (!ok) af[t][e] = (T)0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
+        }
+    }
+    // epilogue: lane = output column, register = output row: each half-wave
+    // adds 128 contiguous bytes (the full-rate atomic shape)
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n2_0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = n1_0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gm < p.N1 && gn < p.N2) atomicAdd(p.C + (size_t)gm * p.ldc + gn, p.alpha * acc[i][j][r]);
+            }
+        }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    dim3 grid(tiles), block(WM * WN * 64);
+#define VLMO_LAUNCH_EPI(E)                                                                     \
+    case E: {                                                                                  \
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E>;                                         \
+        if (LDS > 65536) {                                                                     \
+            static bool attr_set = false;                                                      \
+            if (!attr_set) {                                                                   \
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+                attr_set = true;                                                               \
+            }                                                                                  \
+        }                                                                                      \
+        hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                        \
+    } break;
+    switch (epi) {
+        VLMO_LAUNCH_EPI(EPI_BIAS)
+        VLMO_LAUNCH_EPI(EPI_BIAS_GELU)
+        VLMO_LAUNCH_EPI(EPI_RESID)
+        VLMO_LAUNCH_EPI(EPI_DGELU)
+        VLMO_LAUNCH_EPI(EPI_F32)
+        default:
+            vlmo_set_error("vlmo_gemm_nt: unknown epilogue %d", epi);
+            return -1;
+    }
+#undef VLMO_LAUNCH_EPI
+    VLMO_CHECK_LAUNCH("vlmo_gemm_nt");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
+                            int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream) {
+    VLMO_CHECK_ARG(A && B && e, "vlmo_gemm_nt: null operand");
+    VLMO_CHECK_ARG(M > 0 && N > 0 && K > 0, "vlmo_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+    VLMO_CHECK_ARG(K % 64 == 0, "vlmo_gemm_nt: K=%d must be a multiple of 64", K);
+    VLMO_CHECK_ARG(N % 4 == 0, "vlmo_gemm_nt: N=%d must be a multiple of 4", N);
+    VLMO_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "vlmo_gemm_nt: bad lda/ldb %d/%d", lda, ldb);
+    VLMO_CHECK_ARG(e->out && e->ldo >= N && e->ldo % 4 == 0, "vlmo_gemm_nt: bad output / ldo");
+    VLMO_CHECK_ARG(epi != EPI_BIAS_GELU || (e->out2 && e->ld2 >= N), "vlmo_gemm_nt: gelu epilogue needs out2");
+    VLMO_CHECK_ARG(epi != EPI_RESID || e->resid, "vlmo_gemm_nt: residual epilogue needs resid");
+    VLMO_CHECK_ARG(epi != EPI_DGELU || (e->aux && e->ld2 >= N), "vlmo_gemm_nt: dgelu epilogue needs aux");
+    VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_nt: dtype must be bf16 or f16");
+    GemmNT p{A, B, M, N, K, lda, ldb, *e};
+    if (dtype == VLMO_F16) {
+        if (tile == 1) return launch_nt<f16, 256, 128, 4, 2>(epi, p, stream);
+        return launch_nt<f16, 128, 128, 2, 2>(epi, p, stream);
+    }
+    if (tile == 1) return launch_nt<bf16, 256, 128, 4, 2>(epi, p, stream);
+    return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
+}
+
+extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                            int M, int N1, int N2, float alpha, int splits, hipStream_t stream) {
+    VLMO_CHECK_ARG(A && B && C, "vlmo_gemm_tn: null operand");
+    VLMO_CHECK_ARG(M > 0 && N1 >= 8 && N2 >= 8, "vlmo_gemm_tn: bad problem M=%d N1=%d N2=%d", M, N1, N2);
+    VLMO_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "vlmo_gemm_tn: N1,N2,lda,ldb must be multiples of 8");
+    VLMO_CHECK_ARG(lda >= N1 && ldb >= N2 && ldc >= N2, "vlmo_gemm_tn: leading dimension too small");
+    VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn: dtype must be bf16 or f16");
+    const int nk = (M + 63) / 64;
+    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    if (splits <= 0) {  // aim for ~3 workgroups per CU
+        splits = (768 + tiles - 1) / tiles;
+    }
+    if (splits > nk) splits = nk;
+    const int per = (nk + splits - 1) / splits;
+    splits = (nk + per - 1) / per;
+    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, per, alpha};
+    dim3 grid(tiles, splits), block(256);
+    if (dtype == VLMO_F16)
+        hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, 65536, stream, p);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, 65536, stream, p);
+    VLMO_CHECK_LAUNCH("vlmo_gemm_tn");
+    return 0;
+}

@@ -1,0 +1,209 @@
+"""ctypes binding of libvlmo_hip.so (include/vlmo_hip.h).
+
+PyTorch is used only for device memory and streams: every wrapper takes torch
+tensors, passes raw device pointers + the caller's CURRENT stream to the C-ABI
+and returns immediately (the library only enqueues work).  There is no CPU or
+eager-PyTorch fallback: if the library is missing, importing this module works
+but the first call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvlmo_hip.so')
+
+BF16, F16, F32 = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+
+_vp, _i32, _u32, _u64, _f32 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
+                               ctypes.c_uint64, ctypes.c_float)
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [('out', _vp), ('out2', _vp), ('bias', _vp), ('gamma', _vp),
+                ('resid', _vp), ('row_scale', _vp), ('aux', _vp),
+                ('ldo', _i32), ('ld2', _i32), ('relu', _i32),
+                ('drop_thresh', _u32), ('inv_keep', _f32), ('beta', _f32),
+                ('seed', _u64)]
+
+
+_SIGS = {
+    'vlmo_gemm_nt': [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32,
+                     ctypes.POINTER(Epilogue), _vp],
+    'vlmo_gemm_tn': [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    'vlmo_ln_fwd': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
+    'vlmo_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    'vlmo_attn_fwd': [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _f32,
+                      _u64, _vp],
+    'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f32,
+                      _u32, _f32, _u64, _vp],
+    'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp],
+    'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    'vlmo_cast_weight': [_i32, _vp, _i32, _i32, _vp, _vp, _vp],
+    'vlmo_patchify': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    'vlmo_embed_img_finish': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _u32, _f32,
+                              _u64, _vp],
+    'vlmo_embed_img_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _u32, _f32,
+                           _u64, _vp],
+    'vlmo_embed_txt_fwd': [_vp] * 10 + [_i32, _i32, _i32, _f32, _u32, _f32, _u64, _vp],
+    'vlmo_embed_txt_bwd': [_vp] * 11 + [_i32, _i32, _i32, _u32, _f32, _u64, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build the HIP extension first '
+                '(python -c "import __graft_entry__ as g; g.build()" or '
+                'make -C exploremultimodal_amd/csrc). There is no CPU fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        L.vlmo_last_error.restype = ctypes.c_char_p
+        L.vlmo_abi_version.restype = ctypes.c_int
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = sig
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ['vlmo_last_error', 'vlmo_abi_version'] + list(_SIGS)
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f'{name} failed (rc={rc}): {lib().vlmo_last_error().decode()}')
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    return {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}[t.dtype]
+
+
+def drop_params(p, training):
+    """(thresh, inv_keep) of the counter-based dropout; thresh 0 disables it."""
+    if not training or p <= 0.0:
+        return 0, 1.0
+    thresh = int(round(p * 65536))
+    return thresh, 65536.0 / (65536 - thresh)
+
+
+# ------------------------------------------------------------------ wrappers
+
+def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=None,
+            row_scale=None, aux=None, ldo=None, ld2=None, relu=False, drop=(0, 1.0), seed=0,
+            beta=0.0, tile=0, lda=None, ldb=None):
+    e = Epilogue(_p(out), _p(out2), _p(bias), _p(gamma), _p(resid), _p(row_scale), _p(aux),
+                 ldo if ldo is not None else out.stride(0),
+                 ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else
+                                              (aux.stride(0) if aux is not None else 0)),
+                 int(relu), drop[0], drop[1], beta, seed & 0xFFFFFFFFFFFFFFFF)
+    rc = lib().vlmo_gemm_nt(epi, _dt(A), tile, _p(A), lda if lda is not None else A.stride(0),
+                            _p(B), ldb if ldb is not None else B.stride(0), M, N, K,
+                            ctypes.byref(e), _stream())
+    _check(rc, 'vlmo_gemm_nt')
+
+
+def gemm_tn(A, B, C, M, N1, N2, alpha=1.0, splits=0):
+    rc = lib().vlmo_gemm_tn(_dt(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(C), C.stride(0),
+                            M, N1, N2, alpha, splits, _stream())
+    _check(rc, 'vlmo_gemm_tn')
+
+
+def ln_fwd(x, w, b, y, mean, rstd, rowmap, M, d, eps):
+    rc = lib().vlmo_ln_fwd(_p(x), _p(w), _p(b), _p(y), int(y.dtype == torch.float32), _p(mean),
+                           _p(rstd), _p(rowmap), M, d, eps, _stream())
+    _check(rc, 'vlmo_ln_fwd')
+
+
+def ln_bwd(dy, rowmap, x, w, mean, rstd, dres, dx, dw, db, M, d):
+    rc = lib().vlmo_ln_bwd(_p(dy), int(dy.dtype == torch.float32), _p(rowmap), _p(x), _p(w),
+                           _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), M, d, _stream())
+    _check(rc, 'vlmo_ln_bwd')
+
+
+def attn_fwd(qkv, seg, nseq, keymask, ctx, lse, heads, d, max_len, scale, drop=(0, 1.0), seed=0):
+    rc = lib().vlmo_attn_fwd(_p(qkv), _p(seg), nseq, _p(keymask), _p(ctx), _p(lse),
+                             lse.stride(0) if lse is not None else 0, heads, d, max_len, scale,
+                             drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _check(rc, 'vlmo_attn_fwd')
+
+
+def attn_bwd(qkv, ctx, dctx, lse, seg, nseq, keymask, dqkv, heads, d, max_len, scale,
+             drop=(0, 1.0), seed=0):
+    rc = lib().vlmo_attn_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), lse.stride(0), _p(seg), nseq,
+                             _p(keymask), _p(dqkv), heads, d, max_len, scale, drop[0], drop[1],
+                             seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _check(rc, 'vlmo_attn_bwd')
+
+
+def resid_bwd(dx, zd, gamma, row_scale, dz, dgamma, dbias, M, d, drop=(0, 1.0), seed=0):
+    rc = lib().vlmo_resid_bwd(_p(dx), _p(zd), _p(gamma), _p(row_scale), _p(dz), _p(dgamma),
+                              _p(dbias), M, d, drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF,
+                              _stream())
+    _check(rc, 'vlmo_resid_bwd')
+
+
+def colsum(x, out, M, N):
+    rc = lib().vlmo_colsum(_dt(x), _p(x), x.stride(0), _p(out), M, N, _stream())
+    _check(rc, 'vlmo_colsum')
+
+
+def cast_weight(src, dst, dstT):
+    rows, cols = src.shape
+    ref = dst if dst is not None else dstT
+    rc = lib().vlmo_cast_weight(_dt(ref), _p(src), rows, cols, _p(dst), _p(dstT), _stream())
+    _check(rc, 'vlmo_cast_weight')
+
+
+def patchify(img, out, patch):
+    B, C, H, W = img.shape
+    rc = lib().vlmo_patchify(_p(img), _p(out), B, C, H, W, patch, _stream())
+    _check(rc, 'vlmo_patchify')
+
+
+def embed_img_finish(proj, cls_tok, mask_tok, pos, type_row, masked, x, B, npatch, d,
+                     drop=(0, 1.0), seed=0):
+    rc = lib().vlmo_embed_img_finish(_p(proj), _p(cls_tok), _p(mask_tok), _p(pos), _p(type_row),
+                                     _p(masked), _p(x), B, npatch, d, drop[0], drop[1],
+                                     seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _check(rc, 'vlmo_embed_img_finish')
+
+
+def embed_img_bwd(dx, masked, dproj, dcls, dmask, dpos, dtype_row, B, npatch, d, drop=(0, 1.0),
+                  seed=0):
+    rc = lib().vlmo_embed_img_bwd(_p(dx), _p(masked), _p(dproj), _p(dcls), _p(dmask), _p(dpos),
+                                  _p(dtype_row), B, npatch, d, drop[0], drop[1],
+                                  seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _check(rc, 'vlmo_embed_img_bwd')
+
+
+def embed_txt_fwd(ids, word, pos, btype0, ln_w, ln_b, type0, x, xhat, rstd, B, T, d, eps,
+                  drop=(0, 1.0), seed=0):
+    rc = lib().vlmo_embed_txt_fwd(_p(ids), _p(word), _p(pos), _p(btype0), _p(ln_w), _p(ln_b),
+                                  _p(type0), _p(x), _p(xhat), _p(rstd), B, T, d, eps, drop[0],
+                                  drop[1], seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _check(rc, 'vlmo_embed_txt_fwd')
+
+
+def embed_txt_bwd(dx, ids, xhat, rstd, ln_w, dword, dpos, dbtype0, dln_w, dln_b, dtype0, B, T, d,
+                  drop=(0, 1.0), seed=0):
+    rc = lib().vlmo_embed_txt_bwd(_p(dx), _p(ids), _p(xhat), _p(rstd), _p(ln_w), _p(dword),
+                                  _p(dpos), _p(dbtype0), _p(dln_w), _p(dln_b), _p(dtype0), B, T, d,
+                                  drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _check(rc, 'vlmo_embed_txt_bwd')

@@ -1,0 +1,142 @@
+/* C-ABI of libvlmo_hip.so: the MI355X (gfx950) engine under the VLMo
+ * pretraining forward/backward path of fanzhongyi/ExploreMultiModal.
+ *
+ * The reference has no native/FFI boundary for this path (it is a Python
+ * nn.Module contract: models/build.py:4-12, models/vlmo/vlmo_module.py:395-436,
+ * models/vlmo/vlmo.py:357-414); these entry points are what a binding of that
+ * path to this engine calls.  Each one cites the reference code it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every buffer (including workspaces) is
+ *    owned by the caller and lives in device memory unless stated otherwise;
+ *  - every function only ENQUEUES work on `stream` (asynchronous, graph-capturable,
+ *    no allocation, no synchronisation) and returns 0 on success, <0 for an
+ *    argument error, >0 for a hipError_t; vlmo_last_error() gives the message;
+ *  - token-major activations: row m of an [M, d] matrix is one token; rows are
+ *    "packed" (all text tokens of the batch, then all image tokens) and attention
+ *    finds its keys through per-sequence segment descriptors, so the reference's
+ *    torch.cat([txt, img], dim=1) (vlmo.py:406) never materialises;
+ *  - dropout masks come from a counter-based generator keyed by (seed, element),
+ *    so backward regenerates them; prob = thresh/65536, thresh 0 = disabled.
+ */
+#ifndef VLMO_HIP_H
+#define VLMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+enum { VLMO_BF16 = 0, VLMO_F16 = 1, VLMO_F32 = 2 };
+
+/* GEMM epilogues (fused into the accumulator write-back) */
+enum {
+    VLMO_EPI_BIAS = 0,      /* out[T]   = acc + bias            (relu optional)             */
+    VLMO_EPI_BIAS_GELU = 1, /* out[T]   = u = acc + bias ; out2[T] = dropout(gelu_erf(u))    */
+    VLMO_EPI_RESID = 2,     /* zd = dropout(acc + bias); out2[T] = zd;                        */
+                            /* out[f32] = resid + gamma * zd * row_scale[m]                   */
+    VLMO_EPI_DGELU = 3,     /* out[T]   = dropout_mask(acc) * gelu_erf'(aux[m,n])            */
+    VLMO_EPI_F32 = 4        /* out[f32] = acc + bias + beta * out                             */
+};
+
+typedef struct VlmoEpilogue {
+    void* out;              /* [M, ldo]                                     */
+    void* out2;             /* [M, ld2] (see epilogue table), may be NULL   */
+    const float* bias;      /* [N] or NULL                                  */
+    const float* gamma;     /* [N] layer-scale or NULL (=1)                 */
+    const float* resid;     /* [M, ldo] fp32 residual stream                */
+    const float* row_scale; /* [M] drop-path scale per token or NULL (=1)   */
+    const void* aux;        /* [M, ld2] pre-activation for VLMO_EPI_DGELU   */
+    int32_t ldo, ld2;
+    int32_t relu;
+    uint32_t drop_thresh;   /* round(p * 65536); 0 disables dropout         */
+    float inv_keep;         /* 1 / (1 - p)                                  */
+    float beta;
+    uint64_t seed;
+} VlmoEpilogue;
+
+const char* vlmo_last_error(void);
+int vlmo_abi_version(void);
+
+/* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  tile: 0 = 128x128, 1 = 256x128.
+ * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm
+ * Mlp fc1/fc2 (vlmo.py:141-157, 195-196), the PatchEmbed conv (vlmo.py:304) and,
+ * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */
+int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
+                 int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream);
+
+/* C[N1,N2] += alpha * A[M,N1]^T . B[M,N2]  (fp32 atomic accumulation; weight
+ * gradients of the linears above, i.e. autograd of vlmo.py:76-78,96,195-196). */
+int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                 int M, int N1, int N2, float alpha, int splits, hipStream_t stream);
+
+/* LayerNorm over the last dim (eps = 1e-12 in VLMo: vlmo_module.py:21-23; vlmo.py:188,192,413).
+ * x fp32 [M,d] -> y (bf16, or fp32 when out_f32) at row rowmap[m] (or m), + mean/rstd [M]. */
+int vlmo_ln_fwd(const float* x, const float* w, const float* b, void* y, int out_f32,
+                float* mean, float* rstd, const int32_t* rowmap, int M, int d, float eps,
+                hipStream_t stream);
+/* dx = dres + LN'(dy);  dw += sum dy*xhat;  db += sum dy  (dres may be NULL). */
+int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, const float* x, const float* w,
+                const float* mean, const float* rstd, const float* dres, float* dx, float* dw,
+                float* db, int M, int d, hipStream_t stream);
+
+/* Fused softmax attention over packed rows (vlmo.py:79-95).
+ * qkv [M, 3*d] (q | k | v, head-major inside each third), ctx [M, d].
+ * seg[s] = {rowA, lenA, rowB, lenB}: sequence s = rows [rowA,rowA+lenA) ++ [rowB,rowB+lenB).
+ * keymask [M] int32 (0 = padded key, vlmo.py:89-91) or NULL.  lse [S, heads, NPAD] fp32. */
+int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, const int32_t* keymask,
+                  void* ctx, float* lse, int lse_stride, int heads, int d, int max_len,
+                  float scale, uint32_t drop_thresh, float inv_keep, uint64_t seed,
+                  hipStream_t stream);
+int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                  int lse_stride, const int32_t* seg, int num_seq, const int32_t* keymask,
+                  void* dqkv, int heads, int d, int max_len, float scale, uint32_t drop_thresh,
+                  float inv_keep, uint64_t seed, hipStream_t stream);
+
+/* Residual-branch backward (vlmo.py:194-196): dz = dx * gamma * row_scale * dropmask/(1-p);
+ * dgamma += sum_m dx * row_scale * zd;  dbias += sum_m dz. */
+int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const float* row_scale,
+                   void* dz, float* dgamma, float* dbias, int M, int d, uint32_t drop_thresh,
+                   float inv_keep, uint64_t seed, hipStream_t stream);
+
+/* out[c] += sum_m x[m, c]  (bias gradients), x is bf16/f16 [M, ld]. */
+int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, int N, hipStream_t stream);
+
+/* fp32 -> bf16/f16 weight shadow copies: dst = cast(src), dstT = cast(src)^T (either may be NULL). */
+int vlmo_cast_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT,
+                     hipStream_t stream);
+
+/* Image embedding (vlmo.py:298-319, timm PatchEmbed):
+ *  patchify: image f32 [B,C,H,W] -> bf16 [B*gh*gw, C*p*p] rows ordered (b, py, px), cols (c, ky, kx)
+ *  finish:   x[b,0] = cls + pos[0] + type;  x[b,1+i] = (masked? mask_token : proj[b,i]) + pos[1+i] + type */
+int vlmo_patchify(const float* img, void* out, int B, int C, int H, int W, int patch,
+                  hipStream_t stream);
+int vlmo_embed_img_finish(const void* proj, const float* cls_tok, const float* mask_tok,
+                          const float* pos, const float* type_row, const uint8_t* masked_pos,
+                          float* x, int B, int npatch, int d, uint32_t drop_thresh,
+                          float inv_keep, uint64_t seed, hipStream_t stream);
+/* backward of finish: dproj[b,i] = masked? 0 : g; dcls += ; dmask += ; dpos += ; dtype_row += */
+int vlmo_embed_img_bwd(const float* dx, const uint8_t* masked_pos, void* dproj, float* dcls,
+                       float* dmask, float* dpos, float* dtype_row, int B, int npatch, int d,
+                       uint32_t drop_thresh, float inv_keep, uint64_t seed, hipStream_t stream);
+
+/* Text embedding (vlmo.py:321-324 + transformers BertEmbeddings):
+ *  e = word[ids] + btype0 + pos[t];  x = LN_eps(e) (+dropout) + type0 */
+int vlmo_embed_txt_fwd(const int64_t* ids, const float* word, const float* pos, const float* btype0,
+                       const float* ln_w, const float* ln_b, const float* type0, float* x,
+                       float* xhat, float* rstd, int B, int T, int d, float eps,
+                       uint32_t drop_thresh, float inv_keep, uint64_t seed, hipStream_t stream);
+int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, const float* rstd,
+                       const float* ln_w, float* dword, float* dpos, float* dbtype0, float* dln_w,
+                       float* dln_b, float* dtype0, int B, int T, int d, uint32_t drop_thresh,
+                       float inv_keep, uint64_t seed, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLMO_HIP_H */

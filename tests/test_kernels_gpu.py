@@ -1,0 +1,318 @@
+"""Per-kernel parity of the C-ABI HIP kernels (through exploremultimodal_amd.hip)
+against plain PyTorch fp32 math of the same op on the same bf16-rounded inputs.
+Tolerances (stated per test): bf16 outputs 2^-8 relative (one rounding) plus the
+fp32-accumulation noise; fp32 outputs 1e-3 relative to the row scale."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from exploremultimodal_amd import hip  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _rand(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def _close(got, ref, rtol, atol, what=''):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    bad = err > lim
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(
+            f'{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {err.max().item():.4g} '
+            f'first at {idx}: got {got[tuple(idx)].item():.6g} ref {ref[tuple(idx)].item():.6g}')
+
+
+@pytest.mark.parametrize('tile', [0, 1])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (300, 256, 128), (1000, 384, 768), (77, 128, 192)])
+def test_gemm_nt_exact_integers(tile, M, N, K):
+    """Asymmetric small-integer operands: products and fp32 sums are exact, so any
+    fragment-layout or swizzle error shows up as a wrong integer."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-2, 3, (N, K), generator=g).float()
+    B[:, 0] += torch.arange(N).float() % 5     # break symmetries
+    ref = A @ B.t()
+    Ad, Bd = A.to(DEV).bfloat16(), B.to(DEV).bfloat16()
+    out = torch.full((M, N), float('nan'), device=DEV)
+    hip.gemm_nt(hip.EPI_F32, Ad, Bd, M, N, K, out, tile=tile)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref), (out.cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize('tile', [0, 1])
+def test_gemm_nt_bias_bf16_and_padding_rows(tile):
+    M, N, K = 333, 256, 256
+    A, B = _rand(M, K, seed=1), _rand(N, K, scale=0.1, seed=2)
+    bias = _rand(N, seed=3, dtype=torch.float32)
+    out = torch.full((M + 5, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out, bias=bias, tile=tile)
+    ref = A.float() @ B.float().t() + bias
+    _close(out[:M], ref, 1 / 128, 1e-2, 'bias epilogue')
+    assert (out[M:] == 7.0).all(), 'rows beyond M were written'
+    out2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out2, bias=bias, relu=True, tile=tile)
+    _close(out2, ref.relu(), 1 / 128, 1e-2, 'bias+relu epilogue')
+
+
+def test_gemm_nt_f16_dtype():
+    M, N, K = 200, 128, 128
+    A, B = _rand(M, K, seed=1, dtype=torch.float16), _rand(N, K, scale=0.1, seed=2, dtype=torch.float16)
+    out = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out)
+    _close(out, A.float() @ B.float().t(), 1 / 512, 1e-2, 'f16 gemm')
+
+
+def test_gemm_nt_gelu_resid_dgelu_epilogues():
+    M, N, K = 500, 384, 128
+    A, B = _rand(M, K, seed=4), _rand(N, K, scale=0.15, seed=5)
+    bias = _rand(N, seed=6, dtype=torch.float32) * 0.1
+    acc = A.float() @ B.float().t() + bias
+    # fc1: u and gelu(u)
+    u = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hh = torch.empty_like(u)
+    hip.gemm_nt(hip.EPI_BIAS_GELU, A, B, M, N, K, u, out2=hh, bias=bias)
+    _close(u, acc, 1 / 128, 1e-2, 'gelu.u')
+    _close(hh, F.gelu(acc), 1 / 128, 1e-2, 'gelu.h')
+    # residual: x + gamma * (acc + bias) * row_scale
+    resid = _rand(M, N, seed=7, dtype=torch.float32)
+    gamma = _rand(N, seed=8, dtype=torch.float32)
+    rs = (torch.rand(M, device=DEV) > 0.3).float() / 0.7
+    xo = torch.empty(M, N, device=DEV)
+    zd = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nt(hip.EPI_RESID, A, B, M, N, K, xo, out2=zd, bias=bias, gamma=gamma, resid=resid, row_scale=rs)
+    _close(zd, acc, 1 / 128, 1e-2, 'resid.zd')
+    _close(xo, resid + gamma * acc * rs[:, None], 1e-3, 1e-3, 'resid.out')
+    # dgelu: acc * gelu'(aux)
+    aux = _rand(M, N, seed=9)
+    dg = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nt(hip.EPI_DGELU, A, B, M, N, K, dg, aux=aux)
+    a = aux.float().requires_grad_(True)
+    F.gelu(a).backward(torch.ones_like(a))
+    _close(dg, (A.float() @ B.float().t()) * a.grad, 1 / 128, 1e-2, 'dgelu')
+
+
+def test_dropout_epilogue_consistency_with_backward():
+    """EPI_RESID dropout mask == vlmo_resid_bwd mask; drop rate ~ p; survivors scaled 1/(1-p)."""
+    M, N, K = 512, 256, 64
+    A, B = _rand(M, K, seed=1), _rand(N, K, scale=0.3, seed=2)
+    resid = torch.zeros(M, N, device=DEV)
+    drop = hip.drop_params(0.1, True)
+    xo, zd = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nt(hip.EPI_RESID, A, B, M, N, K, xo, out2=zd, resid=resid, drop=drop, seed=1234)
+    acc = A.float() @ B.float().t()
+    kept = zd.float() != 0
+    rate = 1 - kept.float().mean().item()
+    assert abs(rate - 0.1) < 0.01, rate
+    _close(zd[kept], (acc / 0.9)[kept], 1 / 100, 1e-2, 'dropout survivors')
+    dx = torch.ones(M, N, device=DEV)
+    dz = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.resid_bwd(dx, None, None, None, dz, None, None, M, N, drop=drop, seed=1234)
+    assert torch.equal(dz.float() != 0, kept), 'forward and backward dropout masks differ'
+    zd2 = torch.empty_like(zd)
+    hip.gemm_nt(hip.EPI_RESID, A, B, M, N, K, xo, out2=zd2, resid=resid, drop=drop, seed=99)
+    assert not torch.equal(zd2.float() != 0, kept), 'seed does not change the mask'
+
+
+@pytest.mark.parametrize('M,N1,N2', [(64, 128, 128), (1000, 256, 384), (333, 128, 776), (4096, 768, 768)])
+def test_gemm_tn_wgrad(M, N1, N2):
+    A, B = _rand(M, N1, seed=1), _rand(M, N2, seed=2)
+    C = torch.zeros(N1, N2, device=DEV)
+    hip.gemm_tn(A, B, C, M, N1, N2)
+    ref = A.float().t() @ B.float()
+    _close(C, ref, 2e-3, 2e-3 * math.sqrt(M), 'wgrad')
+    hip.gemm_tn(A, B, C, M, N1, N2, alpha=0.5, splits=3)
+    _close(C, 1.5 * ref, 2e-3, 3e-3 * math.sqrt(M), 'wgrad accumulate')
+
+
+def test_gemm_tn_exact_integers():
+    M, N1, N2 = 200, 128, 256
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-3, 4, (M, N1), generator=g).float()
+    B = torch.randint(-2, 3, (M, N2), generator=g).float()
+    A[0] += torch.arange(N1).float() % 3
+    C = torch.zeros(N1, N2, device=DEV)
+    hip.gemm_tn(A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), C, M, N1, N2, splits=1)
+    assert torch.equal(C.cpu(), A.t() @ B)
+
+
+@pytest.mark.parametrize('M,d', [(37, 128), (1000, 768), (260, 1024), (64, 256)])
+def test_layernorm_fwd_bwd(M, d):
+    x = _rand(M, d, seed=1, dtype=torch.float32) * 2 + 0.5
+    w = _rand(d, seed=2, dtype=torch.float32) * 0.1 + 1
+    b = _rand(d, seed=3, dtype=torch.float32) * 0.1
+    y = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.ln_fwd(x, w, b, y, mean, rstd, None, M, d, 1e-12)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (d,), wr, br, 1e-12)
+    _close(y, ref, 1 / 128, 1e-2, 'ln fwd')
+    _close(mean, x.mean(1), 1e-5, 1e-5, 'ln mean')
+    # fp32 output through a row map (final norm scatter)
+    perm = torch.randperm(M, device=DEV).int()
+    y32 = torch.empty(M, d, device=DEV)
+    hip.ln_fwd(x, w, b, y32, mean, rstd, perm, M, d, 1e-12)
+    _close(y32[perm.long()], ref, 1e-4, 1e-4, 'ln fwd f32 rowmap')
+    # backward
+    dy = _rand(M, d, seed=4)
+    dres = _rand(M, d, seed=5, dtype=torch.float32)
+    ref.backward(dy.float())
+    dx = torch.empty(M, d, device=DEV)
+    dw, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    hip.ln_bwd(dy, None, x, w, mean, rstd, dres, dx, dw, db, M, d)
+    _close(dx, xr.grad + dres, 1e-3, 1e-3, 'ln dx')
+    _close(dw, wr.grad, 1e-3, 1e-3 * math.sqrt(M), 'ln dw')
+    _close(db, br.grad, 1e-3, 1e-3 * math.sqrt(M), 'ln db')
+    # fp32 dy through the row map, no residual
+    dy32 = torch.empty(M, d, device=DEV)
+    dy32[perm.long()] = dy.float()
+    dx2 = torch.empty(M, d, device=DEV)
+    hip.ln_bwd(dy32, perm, x, w, mean, rstd, None, dx2, None, None, M, d)
+    _close(dx2, xr.grad, 1e-3, 1e-3, 'ln dx rowmap')
+
+
+def _attn_case(B, lenA, lenB, heads, seed=0, mask_frac=0.3):
+    """packed rows: all A segments, then all B segments."""
+    d = heads * 64
+    M = B * (lenA + lenB)
+    qkv = _rand(M, 3 * d, seed=seed, scale=1.0)
+    seg = torch.tensor([[b * lenA, lenA, B * lenA + b * lenB, lenB] for b in range(B)], dtype=torch.int32)
+    keymask = torch.ones(M, dtype=torch.int32)
+    g = torch.Generator().manual_seed(seed + 1)
+    for b in range(B):
+        if b % 2 == 1 and lenA > 4:
+            p0 = int(torch.randint(2, lenA, (1,), generator=g))
+            keymask[b * lenA + p0:(b + 1) * lenA] = 0
+    return qkv, seg.to(DEV), keymask.to(DEV), M, d
+
+
+def _attn_ref(qkv, seg, keymask, heads, d, dctx=None):
+    """fp32 torch reference per sequence (vlmo.py:79-95); returns ctx (+ dqkv)."""
+    q = qkv.float().clone().requires_grad_(dctx is not None)
+    ctx = torch.zeros(q.shape[0], d, device=q.device)
+    outs = []
+    for s in seg.tolist():
+        rows = torch.cat([torch.arange(s[0], s[0] + s[1]), torch.arange(s[2], s[2] + s[3])]).to(q.device)
+        x = q[rows]
+        N = x.shape[0]
+        qq, kk, vv = [x[:, i * d:(i + 1) * d].reshape(N, heads, 64).transpose(0, 1) for i in range(3)]
+        att = (qq @ kk.transpose(-2, -1)) * 64 ** -0.5
+        att = att.masked_fill(~keymask[rows].bool()[None, None, :], float('-inf')).softmax(-1)
+        o = (att @ vv).transpose(0, 1).reshape(N, d)
+        outs.append((rows, o))
+    ctx = torch.zeros(q.shape[0], d, device=q.device)
+    for rows, o in outs:
+        ctx = ctx.index_add(0, rows, o)
+    if dctx is None:
+        return ctx.detach()
+    ctx.backward(dctx.float())
+    return ctx.detach(), q.grad
+
+
+@pytest.mark.parametrize('B,lenA,lenB,heads', [(3, 16, 17, 2), (2, 64, 0, 2), (2, 0, 197, 1),
+                                               (2, 64, 197, 2), (1, 40, 197, 3), (2, 24, 50, 4)])
+def test_attention_fwd_bwd(B, lenA, lenB, heads):
+    qkv, seg, keymask, M, d = _attn_case(B, lenA, lenB, heads, seed=B + lenA)
+    N = lenA + lenB
+    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, heads, ((N + 31) // 32) * 32, device=DEV)
+    hip.attn_fwd(qkv, seg, B, keymask, ctx, lse.view(B * heads, -1), heads, d, N, 64 ** -0.5)
+    dctx = _rand(M, d, seed=77)
+    ref_ctx, ref_dqkv = _attn_ref(qkv, seg, keymask, heads, d, dctx)
+    _close(ctx, ref_ctx, 1 / 64, 1e-2, 'attn ctx')
+    dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
+    hip.attn_bwd(qkv, ctx, dctx, lse.view(B * heads, -1), seg, B, keymask, dqkv, heads, d, N, 64 ** -0.5)
+    scale = ref_dqkv.abs().max().item()
+    _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * scale, 'attn dqkv')
+
+
+def test_attention_dropout_statistics():
+    B, lenA, lenB, heads = 2, 64, 197, 2
+    qkv, seg, keymask, M, d = _attn_case(B, lenA, lenB, heads, seed=3)
+    qkv[:, :2 * d] = 0          # uniform attention: ctx = mean of (kept v)/(1-p)
+    ctx0 = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    ctx1 = torch.empty_like(ctx0)
+    lse = torch.zeros(B * heads, 288, device=DEV)
+    hip.attn_fwd(qkv, seg, B, None, ctx0, lse, heads, d, 261, 0.125)
+    hip.attn_fwd(qkv, seg, B, None, ctx1, lse, heads, d, 261, 0.125, drop=hip.drop_params(0.1, True), seed=5)
+    # E[ctx1] = ctx0 ; var small: compare batch means
+    assert abs(ctx1.float().mean().item() - ctx0.float().mean().item()) < 5e-3
+    assert (ctx1.float() - ctx0.float()).abs().mean().item() > 1e-3   # dropout did something
+
+
+def test_colsum_cast_patchify():
+    M, N = 1000, 768
+    x = _rand(M, N, seed=1)
+    out = torch.zeros(N, device=DEV)
+    hip.colsum(x, out, M, N)
+    _close(out, x.float().sum(0), 1e-3, 1e-2, 'colsum')
+    w = _rand(300, 200, seed=2, dtype=torch.float32)
+    a = torch.empty(300, 200, device=DEV, dtype=torch.bfloat16)
+    at = torch.empty(200, 300, device=DEV, dtype=torch.bfloat16)
+    hip.cast_weight(w, a, at)
+    assert torch.equal(a, w.bfloat16()) and torch.equal(at, w.bfloat16().t().contiguous())
+    img = _rand(2, 3, 64, 64, seed=3, dtype=torch.float32)
+    p = torch.empty(2 * 16, 3 * 256, device=DEV, dtype=torch.bfloat16)
+    hip.patchify(img, p, 16)
+    ref = F.unfold(img, 16, stride=16).transpose(1, 2).reshape(32, 768)
+    assert torch.equal(p, ref.bfloat16())
+
+
+def test_embed_img_fwd_bwd():
+    B, npatch, d = 3, 16, 128
+    proj = _rand(B * npatch, d, seed=1)
+    cls_tok, mask_tok = [_rand(d, seed=s, dtype=torch.float32) for s in (2, 3)]
+    pos = _rand(npatch + 1, d, seed=4, dtype=torch.float32)
+    type_row = _rand(d, seed=5, dtype=torch.float32)
+    masked = (torch.rand(B, npatch) < 0.4).to(torch.uint8).to(DEV)
+    x = torch.empty(B, npatch + 1, d, device=DEV)
+    hip.embed_img_finish(proj, cls_tok, mask_tok, pos, type_row, masked, x, B, npatch, d)
+    pr = proj.float().view(B, npatch, d).clone().requires_grad_(True)
+    leaves = [t.clone().requires_grad_(True) for t in (cls_tok, mask_tok, pos, type_row)]
+    w = masked.float().unsqueeze(-1)
+    xr = pr * (1 - w) + leaves[1] * w
+    xr = torch.cat([leaves[0].expand(B, 1, d), xr], 1) + leaves[2] + leaves[3]
+    _close(x, xr, 1e-6, 1e-6, 'embed_img fwd')
+    dx = _rand(B, npatch + 1, d, seed=6, dtype=torch.float32)
+    xr.backward(dx)
+    dproj = torch.empty(B * npatch, d, device=DEV, dtype=torch.bfloat16)
+    dcls, dmask, dtype_row = [torch.zeros(d, device=DEV) for _ in range(3)]
+    dpos = torch.zeros(npatch + 1, d, device=DEV)
+    hip.embed_img_bwd(dx, masked, dproj, dcls, dmask, dpos, dtype_row, B, npatch, d)
+    _close(dproj.view(B, npatch, d), pr.grad, 1 / 128, 1e-3, 'dproj')
+    for got, leaf, name in ((dcls, leaves[0], 'dcls'), (dmask, leaves[1], 'dmask'),
+                            (dpos, leaves[2], 'dpos'), (dtype_row, leaves[3], 'dtype')):
+        _close(got, leaf.grad, 1e-4, 1e-4, name)
+
+
+def test_embed_txt_fwd_bwd():
+    B, T, d, V = 3, 16, 128, 50
+    ids = torch.randint(0, V, (B, T)).to(DEV)
+    ids[0, 5:] = 0
+    tabs = [_rand(V, d, seed=1, dtype=torch.float32), _rand(T, d, seed=2, dtype=torch.float32),
+            _rand(d, seed=3, dtype=torch.float32), _rand(d, seed=4, dtype=torch.float32) * 0.1 + 1,
+            _rand(d, seed=5, dtype=torch.float32), _rand(d, seed=6, dtype=torch.float32)]
+    word, pos, bt0, lw, lb, t0 = tabs
+    x = torch.empty(B * T, d, device=DEV)
+    xhat, rstd = torch.empty(B * T, d, device=DEV), torch.empty(B * T, device=DEV)
+    hip.embed_txt_fwd(ids, word, pos, bt0, lw, lb, t0, x, xhat, rstd, B, T, d, 1e-12)
+    L = [t.clone().requires_grad_(True) for t in tabs]
+    e = F.embedding(ids, L[0], padding_idx=0) + L[2] + L[1][:T]
+    xr = F.layer_norm(e, (d,), L[3], L[4], 1e-12) + L[5]
+    _close(x.view(B, T, d), xr, 1e-4, 1e-4, 'embed_txt fwd')
+    dx = _rand(B * T, d, seed=7, dtype=torch.float32)
+    xr.backward(dx.view(B, T, d))
+    outs = [torch.zeros_like(t) for t in tabs]
+    hip.embed_txt_bwd(dx, ids, xhat, rstd, lw, outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], B, T, d)
+    for got, leaf, name in zip(outs, L, ('dword', 'dpos', 'dbtype0', 'dlnw', 'dlnb', 'dtype0')):
+        _close(got, leaf.grad, 1e-3, 1e-3, name)
