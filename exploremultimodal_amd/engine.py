@@ -93,8 +93,9 @@ class BlockMeta:
     """Static (non-tensor) description of one Block call."""
 
     def __init__(self, plan, heads, d, hidden, fused, expert_ranges, training, drop, attn_drop,
-                 row_scale1, row_scale2, seed):
+                 row_scale1, row_scale2, seed, eps=LN_EPS):
         self.plan, self.heads, self.d, self.hidden = plan, heads, d, hidden
+        self.eps = eps
         self.fused = fused
         self.expert_ranges = expert_ranges      # [(row0, nrows)], one per expert in param order
         self.training = training
@@ -124,11 +125,11 @@ class BlockFn(torch.autograd.Function):
         M, dev = x.shape[0], x.device
         bf, f32 = torch.bfloat16, torch.float32
         sh = meta.shadows
-        need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        need_bwd = any(ctx.needs_input_grad)   # grad mode is off inside forward; this reflects the caller's
         seed = meta.seed
 
         y1, mean1, rstd1 = _empty((M, d), bf, dev), _empty((M,), f32, dev), _empty((M,), f32, dev)
-        hip.ln_fwd(x, n1w, n1b, y1, mean1, rstd1, None, M, d, LN_EPS)
+        hip.ln_fwd(x, n1w, n1b, y1, mean1, rstd1, None, M, d, meta.eps)
         qkv_bias = torch.cat([q_bias.detach(), torch.zeros_like(q_bias), v_bias.detach()])   # vlmo.py:72-75
         qkv = _empty((M, 3 * d), bf, dev)
         hip.gemm_nt(hip.EPI_BIAS, y1, sh.get(qkv_w)[0], M, 3 * d, d, qkv, bias=qkv_bias, tile=meta.tile)
@@ -146,7 +147,7 @@ class BlockFn(torch.autograd.Function):
         hip.gemm_nt(hip.EPI_RESID, ctxb, sh.get(proj_w)[0], M, d, d, x1, out2=zd1, bias=proj_b, gamma=g1,
                     resid=x, row_scale=meta.rs1, drop=meta.drop, seed=seed + 1, tile=meta.tile)
         y2, mean2, rstd2 = _empty((M, d), bf, dev), _empty((M,), f32, dev), _empty((M,), f32, dev)
-        hip.ln_fwd(x1, n2w, n2b, y2, mean2, rstd2, None, M, d, LN_EPS)
+        hip.ln_fwd(x1, n2w, n2b, y2, mean2, rstd2, None, M, d, meta.eps)
         u, hh = _empty((M, hid), bf, dev), _empty((M, hid), bf, dev)
         x2 = _empty((M, d), f32, dev)
         zd2 = _empty((M, d), bf, dev) if need_bwd else None
@@ -224,11 +225,11 @@ class FinalNormFn(torch.autograd.Function):
     """self.norm (vlmo.py:413) writing the [B, T+P, d] fp32 output through the row map."""
 
     @staticmethod
-    def forward(ctx, x, w, b, plan, out_shape):
+    def forward(ctx, x, w, b, plan, out_shape, eps=LN_EPS):
         M, d = x.shape
         out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
         mean, rstd = torch.empty(M, device=x.device), torch.empty(M, device=x.device)
-        hip.ln_fwd(x, w, b, out, mean, rstd, plan.rowmap, M, d, LN_EPS)
+        hip.ln_fwd(x, w, b, out, mean, rstd, plan.rowmap, M, d, eps)
         ctx.plan = plan
         ctx.save_for_backward(x, w, mean, rstd)
         return out
@@ -241,7 +242,7 @@ class FinalNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, db = torch.zeros_like(w), torch.zeros_like(w)
         hip.ln_bwd(dout, ctx.plan.rowmap, x, w, mean, rstd, None, dx, dw, db, M, d)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class EmbedFn(torch.autograd.Function):
@@ -263,7 +264,7 @@ class EmbedFn(torch.autograd.Function):
             xhat = torch.empty((pl.nt, d), dtype=torch.float32, device=dev)
             rstd = torch.empty((pl.nt,), dtype=torch.float32, device=dev)
             hip.embed_txt_fwd(ids, word, tpos, btype[0], ln_w, ln_b, type_emb[0], x[:pl.nt], xhat, rstd, B, T, d,
-                              LN_EPS, drop=drop, seed=seed + 1)
+                              meta['txt_eps'], drop=drop, seed=seed + 1)
             saved['txt'] = (xhat, rstd)
         if P:
             npatch = P - 1
@@ -316,7 +317,7 @@ class EmbedFn(torch.autograd.Function):
             hip.gemm_tn(dproj, patches, dpw, B * npatch, d, patches.shape[1])
             hip.colsum(dproj, dpb, B * npatch, d)
             g[0], g[1] = dpw.view_as(patch_w), dpb
-            g[2], g[4] = dcls.view(1, 1, d), dpos.view(1, P, d)
-            g[3] = dmask.view(1, 1, d) if meta['masked'] is not None else None
+            g[2], g[4] = dcls, dpos
+            g[3] = dmask if meta['masked'] is not None else None
         g[5] = dtype_emb
         return (None, *g)
