@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: image-text pairs/s, forward+backward, VLMo-Base, bf16, on
+1/2/4/8 MI355X (BASELINE.json configs[1] / configs[2]).
+
+A "step" = one VLMO.forward_features(img, txt, masks) in VL mode (training-mode
+semantics: dropout / attention dropout / drop-path 0.1 as conf/model/vlmo_base.yaml:23-25)
++ backward from a scalar loss, on a synthetic batch already resident in HBM.
+For N > 1 every rank runs the same per-GPU batch (weak scaling) and gradients are
+averaged over RCCL (exploremultimodal_amd/dp.py).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from functools import partial
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def fwd_flops_per_pair(d, L, F, T, P=197, patch_k=768):
+    """matmul flops only, 2 per MAC."""
+    blk = lambda n: 24 * n * d * d + 4 * n * n * d
+    return 2 * (P - 1) * patch_k * d + F * (blk(P) + blk(T)) + (L - F) * blk(P + T)
+
+
+def build_model(preset, device, drop=0.1):
+    from exploremultimodal_amd.vlmo import VLMO, LayerNorm
+    from oracle import synth   # config presets only (shapes); no oracle compute on this path
+    mc = synth.make_config(preset).model
+    torch.manual_seed(0)
+    m = VLMO(img_size=mc.img_size, patch_size=mc.patch_size, in_chans=mc.in_chans, num_classes=0,
+             embed_dim=mc.embed_dim, depth=mc.depth, num_heads=mc.num_heads, mlp_ratio=mc.mlp_ratio,
+             qkv_bias=True, drop_rate=drop, attn_drop_rate=drop, drop_path_rate=drop,
+             norm_layer=partial(LayerNorm, eps=1e-12), init_values=mc.init_values, vocab_size=mc.vocab_size,
+             max_text_len=mc.max_text_len, fusion_layer=mc.fusion_layer)
+    for b in m.blocks[:mc.fusion_layer]:       # VlmoModule._freeze_params, vlmo_module.py:165-167
+        del b.mlp['vl']
+    return m.to(device), mc
+
+
+def cpu_baseline(preset, B=8, reps=3):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference) timed on the host cores:
+    VL forward+backward, same shapes, batch B.  Reported baseline, not a target."""
+    from oracle import synth, vlmo_oracle
+    # the GPU box exposes many more logical CPUs than this job's share: use the affinity mask, capped at
+    # the documented 16-core share of a 1-GPU box (oversubscribing the host stalls for minutes)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    mc = synth.make_config(preset).model
+    sd = synth.synth_backbone_state_dict(mc, 0)
+    for t in sd.values():
+        t.requires_grad_(True)
+    batch = synth.synth_batch(mc, B, seed=1234, mim=False)
+    im = torch.ones(B, synth.num_img_tokens(mc), dtype=torch.int64)
+    ts = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        x, _ = vlmo_oracle.forward_features(sd, mc, img=batch['image'], txt=batch['text_ids'], img_attn_masks=im,
+                                            txt_attn_masks=batch['text_mask'])
+        x.square().mean().backward()
+        ts.append(time.perf_counter() - t0)
+        for t in sd.values():
+            t.grad = None
+    ts = sorted(ts[1:])
+    med = ts[len(ts) // 2]
+    return {'value': round(B / med, 3), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle VLMo-Base VL fwd+bwd fp32, batch {B}, median of {reps} after 1 warm-up '
+                      f'({med:.2f} s per step)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (pairs)')
+    ap.add_argument('--preset', default='base')
+    ap.add_argument('--tile', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dropout', action='store_true')
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from exploremultimodal_amd import engine, hip
+    from oracle import synth
+    hip.lib()
+    model, mc = build_model(args.preset, dev, drop=0.0 if args.no_dropout else 0.1)
+    model.train()
+    if args.tile is not None:
+        engine.DEFAULT_TILE = args.tile
+    reducer = None
+    if world > 1:
+        from exploremultimodal_amd.dp import GradReducer
+        reducer = GradReducer(model, dist.group.WORLD)
+
+    B = args.batch
+    batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=False)
+    P = synth.num_img_tokens(mc)
+    img = batch['image'].to(dev)
+    ids, tmask = batch['text_ids'].to(dev), batch['text_mask'].to(dev)
+    imask = torch.ones(B, P, dtype=torch.int64, device=dev)
+    R = torch.randn(B, mc.max_text_len + P, mc.embed_dim, device=dev) / (B * 1000.0)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        x, _ = model.forward_features(img=img, txt=ids, img_attn_masks=imask, txt_attn_masks=tmask)
+        loss = (x * R).sum()
+        if reducer is not None:
+            reducer.prepare()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f'[bench +{time.perf_counter() - t_start:.1f}s] {msg}', file=sys.stderr, flush=True)
+
+    log('model and batch ready')
+    for i in range(args.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log('first step done')
+    barrier()
+    log('warm-up done')
+    hip.PROFILE = {}                      # HIP-event pairs around the GEMM launches of the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(loss).item(), 'non-finite loss'
+
+    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        pairs = B * world * args.steps / dt
+        fl = 3 * fwd_flops_per_pair(mc.embed_dim, mc.depth, mc.fusion_layer, mc.max_text_len, P,
+                                    mc.in_chans * mc.patch_size ** 2)
+        # dominant kernel: per-symbol totals from the event pairs recorded in the timed region
+        per = {}
+        for key, evs in prof.items():
+            sym, flops = key[0], key[1]
+            tot = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+            e = per.setdefault(sym, [0.0, 0.0, 0])
+            e[0] += tot
+            e[1] += flops * len(evs)
+            e[2] += len(evs)
+        dom = max(per.items(), key=lambda kv: kv[1][0]) if per else None
+        roof = None
+        if dom:
+            sym, (tsec, flops, n) = dom
+            ach = flops / tsec / 1e12
+            roof = {'bound': 'mfma', 'kernel': sym, 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'launches_per_step': n // args.steps, 'avg_launch_us': round(tsec / n * 1e6, 2),
+                    'flops_per_launch': round(flops / n)}
+        out = {
+            'metric': 'image-text pairs/sec fwd+bwd, VLMo-Base, 1/2/4/8 MI355X; % bf16 MFMA roofline',
+            'value': round(pairs, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'VLMo-{args.preset} VL forward_features fwd+bwd, per-GPU batch {B} synthetic '
+                                   f'224x224 image + {mc.max_text_len}-token text pairs, dropout/drop-path '
+                                   f'{0.0 if args.no_dropout else 0.1}',
+                       'global_batch': B * world, 'seq_len': mc.max_text_len + P,
+                       'parallelism': f'dp{world}'},
+            'step_tflops': round(fl * B * world * args.steps / dt / 1e12, 1),
+            'step_mfma_frac': round(fl * B * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            'flops_per_pair': fl,
+            'roofline': roof,
+            'kernels': {k: {'s_per_step': round(v[0] / args.steps, 6), 'tflops': round(v[1] / v[0] / 1e12, 1)}
+                        for k, v in per.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.preset)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -16,6 +16,7 @@ import torch
 from . import hip
 
 LN_EPS = 1e-12          # vlmo_module.py:21-23
+DEFAULT_TILE = 0         # GEMM tile: 0 = 128x128 (2 workgroups/CU), 1 = 256x128
 
 
 class ShadowCache:
@@ -104,7 +105,7 @@ class BlockMeta:
         self.rs1, self.rs2 = row_scale1, row_scale2
         self.seed = seed
         self.shadows = None
-        self.tile = 0
+        self.tile = DEFAULT_TILE
 
 
 def _empty(shape, dtype, dev):

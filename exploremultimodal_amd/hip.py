@@ -52,6 +52,9 @@ _SIGS = {
 }
 
 _lib = None
+# bench.py sets this to a dict to collect (start, end) event pairs around GEMM launches,
+# keyed by (kernel symbol, algorithmic flops of the launch)
+PROFILE = None
 
 
 def lib():
@@ -113,15 +116,29 @@ def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=
                  ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else
                                               (aux.stride(0) if aux is not None else 0)),
                  int(relu), drop[0], drop[1], beta, seed & 0xFFFFFFFFFFFFFFFF)
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = lib().vlmo_gemm_nt(epi, _dt(A), tile, _p(A), lda if lda is not None else A.stride(0),
                             _p(B), ldb if ldb is not None else B.stride(0), M, N, K,
                             ctypes.byref(e), _stream())
+    if ev is not None:
+        ev[1].record()
+        PROFILE.setdefault((f'gemm_nt_kernel<epi={epi},tile={tile}>', 2 * M * N * K), []).append(ev)
     _check(rc, 'vlmo_gemm_nt')
 
 
 def gemm_tn(A, B, C, M, N1, N2, alpha=1.0, splits=0):
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = lib().vlmo_gemm_tn(_dt(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(C), C.stride(0),
                             M, N1, N2, alpha, splits, _stream())
+    if ev is not None:
+        ev[1].record()
+        PROFILE.setdefault(('gemm_tn_kernel', 2 * M * N1 * N2), []).append(ev)
     _check(rc, 'vlmo_gemm_tn')
 
 
