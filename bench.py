@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--tile', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropout', action='store_true')
+    ap.add_argument('--force-reducer', action='store_true', help='run the RCCL gradient reducer even at world size 1')
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -107,8 +108,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_reducer:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
 
     from exploremultimodal_amd import engine, hip
@@ -119,7 +122,7 @@ def main():
     if args.tile is not None:
         engine.DEFAULT_TILE = args.tile
     reducer = None
-    if world > 1:
+    if dist is not None:
         from exploremultimodal_amd.dp import GradReducer
         reducer = GradReducer(model, dist.group.WORLD)
 
@@ -137,7 +140,7 @@ def main():
         x, _ = model.forward_features(img=img, txt=ids, img_attn_masks=imask, txt_attn_masks=tmask)
         loss = (x * R).sum()
         if reducer is not None:
-            reducer.prepare()
+            reducer.prepare(loss)
         loss.backward()
         if reducer is not None:
             reducer.finish()

@@ -20,6 +20,25 @@ extern "C" int vlmo_abi_version(void) { return 1; }
 
 namespace {
 
+// out0[c] += sum_b ws[b][c] (c < n0) ; out1[c - n0] += ... (c >= n0).  block (64, 4), grid (ncols/64, S)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk, int ncols,
+                                                              float* __restrict__ out0, int n0,
+                                                              float* __restrict__ out1, int rows_per_slice) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int r0 = blockIdx.y * rows_per_slice, r1 = min(nblk, r0 + rows_per_slice);
+    float a = 0.f;
+    if (c < ncols)
+        for (int r = r0 + threadIdx.y; r < r1; r += 4) a += ws[(size_t)r * ncols + c];
+    red[threadIdx.y][threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < ncols) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float* o = c < n0 ? (out0 ? out0 + c : nullptr) : (out1 ? out1 + (c - n0) : nullptr);
+        if (o) atomicAdd(o, t);
+    }
+}
+
 template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
 template <> __device__ __forceinline__ f32x4 ld4<bf16>(const bf16* p) {
     const bf16x4 v = *(const bf16x4*)p;
@@ -37,51 +56,62 @@ template <> __device__ __forceinline__ void st4<f16>(f16* p, f32x4 v) {
     *(f16x4*)p = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
 }
 
-// block = (d/4, RY); thread owns 4 columns, strides over rows of its block's chunk
+// block = (d/4, RY); thread owns 4 columns and every RY-th row of its block's chunk,
+// two rows in flight per thread (independent loads) for memory-level parallelism
 __global__ void resid_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ zd,
                                  const float* __restrict__ gamma, const float* __restrict__ row_scale,
-                                 bf16* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbias, int M,
+                                 bf16* __restrict__ dz, float* __restrict__ ws, bool need_gamma, int M,
                                  int d, int rows_per_block, uint32_t thresh, float inv_keep, uint64_t seed) {
     extern __shared__ float red[];   // [RY][2][d]
-    const int c4 = threadIdx.x * 4;
+    const int c4 = threadIdx.x * 4, RY = blockDim.y;
     const f32x4 g = gamma ? *(const f32x4*)(gamma + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
     f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = ag;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int m = r0 + threadIdx.y; m < r1; m += blockDim.y) {
-        const size_t o = (size_t)m * d + c4;
-        const f32x4 gx = *(const f32x4*)(dx + o);
-        const float rs = row_scale ? row_scale[m] : 1.f;
-        f32x4 v = gx * g * rs;
-        if (thresh) {
-            const uint64_t bits = drop_bits4(seed, ((uint64_t)m * d + c4) >> 2);
+    for (int mb = r0 + threadIdx.y; mb < r1; mb += 2 * RY) {
+        f32x4 gx[2], z[2];
+        float rs[2];
+        bool ok[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, thresh) ? v[j] * inv_keep : 0.f;
+        for (int k = 0; k < 2; ++k) {
+            const int m = mb + k * RY;
+            ok[k] = m < r1;
+            const size_t o = (size_t)(ok[k] ? m : mb) * d + c4;
+            gx[k] = *(const f32x4*)(dx + o);
+            z[k] = need_gamma ? ld4<bf16>(zd + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rs[k] = row_scale ? row_scale[ok[k] ? m : mb] : 1.f;
         }
-        st4<bf16>(dz + o, v);
-        if (dgamma) ag += gx * rs * ld4<bf16>(zd + o);
-        ab += v;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!ok[k]) continue;
+            const int m = mb + k * RY;
+            const size_t o = (size_t)m * d + c4;
+            f32x4 v = gx[k] * g * rs[k];
+            if (thresh) {
+                const uint64_t bits = drop_bits4(seed, ((uint64_t)m * d + c4) >> 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, thresh) ? v[j] * inv_keep : 0.f;
+            }
+            st4<bf16>(dz + o, v);
+            ag += gx[k] * rs[k] * z[k];
+            ab += v;
+        }
     }
-    float* myg = red + (threadIdx.y * 2 + 0) * d + c4;
-    float* myb = red + (threadIdx.y * 2 + 1) * d + c4;
-    *(f32x4*)myg = ag;
-    *(f32x4*)myb = ab;
+    *(f32x4*)(red + (threadIdx.y * 2 + 0) * d + c4) = ag;
+    *(f32x4*)(red + (threadIdx.y * 2 + 1) * d + c4) = ab;
     __syncthreads();
     if (threadIdx.y == 0) {
-        for (int y = 1; y < blockDim.y; ++y) {
+        for (int y = 1; y < RY; ++y) {
             ag += *(const f32x4*)(red + (y * 2 + 0) * d + c4);
             ab += *(const f32x4*)(red + (y * 2 + 1) * d + c4);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (dgamma) atomicAdd(dgamma + c4 + j, ag[j]);
-            if (dbias) atomicAdd(dbias + c4 + j, ab[j]);
-        }
+        *(f32x4*)(ws + (size_t)blockIdx.x * 2 * d + c4) = ag;
+        *(f32x4*)(ws + (size_t)blockIdx.x * 2 * d + d + c4) = ab;
     }
 }
 
-// block (64, 4): 64 column groups of 8 x 4 row lanes
+// block (64, 4): 64 column groups of 8 x 4 row lanes, 4 rows in flight per thread
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int M,
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ ws, int M,
                                                      int N, int rows_per_block) {
     typedef typename Elem<T>::v8 v8;
     __shared__ float red[4][64][8];
@@ -89,10 +119,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     if (c8 < N) {
-        for (int m = r0 + threadIdx.y; m < r1; m += 4) {
-            const v8 v = *(const v8*)(x + (size_t)m * ld + c8);
+        for (int mb = r0 + threadIdx.y; mb < r1; mb += 16) {
+            v8 v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            for (int k = 0; k < 4; ++k) {
+                const int m = mb + 4 * k;
+                v[k] = *(const v8*)(x + (size_t)(m < r1 ? m : mb) * ld + c8);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (mb + 4 * k < r1)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)v[k][j];
         }
     }
 #pragma unroll
@@ -101,8 +139,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     if (threadIdx.y == 0 && c8 < N) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            atomicAdd(out + c8 + j, red[0][threadIdx.x][j] + red[1][threadIdx.x][j] + red[2][threadIdx.x][j] +
-                                        red[3][threadIdx.x][j]);
+            ws[(size_t)blockIdx.y * N + c8 + j] = red[0][threadIdx.x][j] + red[1][threadIdx.x][j] +
+                                                  red[2][threadIdx.x][j] + red[3][threadIdx.x][j];
     }
 }
 
@@ -341,6 +379,22 @@ __global__ __launch_bounds__(256) void embed_txt_bwd_kernel(const float* __restr
     }
 }
 
+}  // namespace
+
+int reduce_partials(const float* ws, int nblk, int ncols, float* out0, int n0, float* out1, hipStream_t stream) {
+    int slices = nblk >= 64 ? 8 : 1;
+    const int rps = (nblk + slices - 1) / slices;
+    slices = (nblk + rps - 1) / rps;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncols + 63) / 64, slices), dim3(64, 4), 0, stream, ws, nblk, ncols,
+                       out0, n0, out1, rps);
+    VLMO_CHECK_LAUNCH("reduce_partials");
+    return 0;
+}
+
+extern "C" int64_t vlmo_reduce_ws_bytes(int ncols) { return reduce_ws_need(ncols); }
+
+namespace {
+
 int rows_per_block_for(int M, int target_blocks, int mult) {
     int r = (M + target_blocks - 1) / target_blocks;
     r = ((r + mult - 1) / mult) * mult;
@@ -351,39 +405,45 @@ int rows_per_block_for(int M, int target_blocks, int mult) {
 
 extern "C" int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const float* row_scale, void* dz,
                               float* dgamma, float* dbias, int M, int d, uint32_t drop_thresh, float inv_keep,
-                              uint64_t seed, hipStream_t stream) {
+                              uint64_t seed, float* ws, int64_t ws_bytes, hipStream_t stream) {
     VLMO_CHECK_ARG(dx && dz, "vlmo_resid_bwd: null pointer");
     VLMO_CHECK_ARG(!dgamma || zd, "vlmo_resid_bwd: dgamma needs zd");
     VLMO_CHECK_ARG(M > 0 && d % 4 == 0 && d >= 4 && d <= 4096, "vlmo_resid_bwd: bad shape M=%d d=%d", M, d);
+    VLMO_CHECK_ARG(ws && ws_bytes >= reduce_ws_need(2 * d), "vlmo_resid_bwd: workspace too small (need %lld bytes)",
+                   (long long)reduce_ws_need(2 * d));
     const int tx = d / 4;
-    int ry = 256 / tx;
+    int ry = 1024 / tx;
     if (ry < 1) ry = 1;
-    if (ry > 8) ry = 8;
-    const int rpb = rows_per_block_for(M, 1024, ry * 4);
+    if (ry > 4) ry = 4;
+    const int rpb = rows_per_block_for(M, VLMO_MAX_PARTIAL_BLOCKS, ry * 2);
     const int grid = (M + rpb - 1) / rpb;
     hipLaunchKernelGGL(resid_bwd_kernel, dim3(grid), dim3(tx, ry), ry * 2 * d * sizeof(float), stream, dx,
-                       (const bf16*)zd, gamma, row_scale, (bf16*)dz, dgamma, dbias, M, d, rpb, drop_thresh, inv_keep,
-                       seed);
+                       (const bf16*)zd, gamma, row_scale, (bf16*)dz, ws, dgamma != nullptr, M, d, rpb, drop_thresh,
+                       inv_keep, seed);
     VLMO_CHECK_LAUNCH("vlmo_resid_bwd");
+    if (dgamma || dbias) return reduce_partials(ws, grid, 2 * d, dgamma, d, dbias, stream);
     return 0;
 }
 
-extern "C" int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, int N, hipStream_t stream) {
+extern "C" int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, int N, float* ws, int64_t ws_bytes,
+                           hipStream_t stream) {
     VLMO_CHECK_ARG(x && out, "vlmo_colsum: null pointer");
     VLMO_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0 && ld >= N, "vlmo_colsum: bad shape M=%d N=%d ld=%d", M, N, ld);
+    VLMO_CHECK_ARG(ws && ws_bytes >= reduce_ws_need(N), "vlmo_colsum: workspace too small (need %lld bytes)",
+                   (long long)reduce_ws_need(N));
     const int gx = (N / 8 + 63) / 64;
-    const int rpb = rows_per_block_for(M, (1024 + gx - 1) / gx, 16);
+    const int rpb = rows_per_block_for(M, VLMO_MAX_PARTIAL_BLOCKS, 16);
     dim3 grid(gx, (M + rpb - 1) / rpb), block(64, 4);
     if (dtype == VLMO_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, stream, (const bf16*)x, ld, out, M, N, rpb);
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, stream, (const bf16*)x, ld, ws, M, N, rpb);
     else if (dtype == VLMO_F16)
-        hipLaunchKernelGGL(colsum_kernel<f16>, grid, block, 0, stream, (const f16*)x, ld, out, M, N, rpb);
+        hipLaunchKernelGGL(colsum_kernel<f16>, grid, block, 0, stream, (const f16*)x, ld, ws, M, N, rpb);
     else {
         vlmo_set_error("vlmo_colsum: dtype must be bf16 or f16");
         return -1;
     }
     VLMO_CHECK_LAUNCH("vlmo_colsum");
-    return 0;
+    return reduce_partials(ws, grid.y, N, out, N, nullptr, stream);
 }
 
 extern "C" int vlmo_cast_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT,

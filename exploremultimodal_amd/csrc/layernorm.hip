@@ -68,8 +68,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
-                                                     float* __restrict__ dw, float* __restrict__ db, int M, int d,
-                                                     int rows_per_block) {
+                                                     float* __restrict__ ws, int M, int d, int rows_per_block) {
     __shared__ float red[4][2][VPL * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -141,8 +140,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const int i = c >> 2, idx = ((i >> 6) * 64 + (i & 63)) * 4 + (c & 3);
         const float sw = red[0][0][idx] + red[1][0][idx] + red[2][0][idx] + red[3][0][idx];
         const float sb = red[0][1][idx] + red[1][1][idx] + red[2][1][idx] + red[3][1][idx];
-        if (dw) atomicAdd(dw + c, sw);
-        if (db) atomicAdd(db + c, sb);
+        if (ws) {
+            ws[(size_t)blockIdx.x * 2 * d + c] = sw;
+            ws[(size_t)blockIdx.x * 2 * d + d + c] = sb;
+        }
     }
 }
 
@@ -172,19 +173,23 @@ extern "C" int vlmo_ln_fwd(const float* x, const float* w, const float* b, void*
 
 extern "C" int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, const float* x, const float* w,
                            const float* mean, const float* rstd, const float* dres, float* dx, float* dw, float* db,
-                           int M, int d, hipStream_t stream) {
+                           int M, int d, float* ws, int64_t ws_bytes, hipStream_t stream) {
     VLMO_CHECK_ARG(dy && x && w && mean && rstd && dx, "vlmo_ln_bwd: null pointer");
     VLMO_CHECK_ARG(M > 0 && d > 0 && d % 4 == 0 && d <= 1024, "vlmo_ln_bwd: need 0 < d <= 1024, d %% 4 == 0 (d=%d, M=%d)", d, M);
+    const bool need_w = dw || db;
+    VLMO_CHECK_ARG(!need_w || (ws && ws_bytes >= reduce_ws_need(2 * d)),
+                   "vlmo_ln_bwd: workspace too small (need %lld bytes)", (long long)reduce_ws_need(2 * d));
+    if (!need_w) ws = nullptr;
     const int vpl = (d / 4 + 63) / 64;
-    int rpb = (M + 1023) / 1024;          // ~1024 workgroups
+    int rpb = (M + VLMO_MAX_PARTIAL_BLOCKS - 1) / VLMO_MAX_PARTIAL_BLOCKS;
     rpb = ((rpb + 3) / 4) * 4;
     if (rpb < 8) rpb = 8;
     const int grid = (M + rpb - 1) / rpb;
 #define LNB(V)                                                                                         \
     if (dy_f32)                                                                                        \
-        hipLaunchKernelGGL((ln_bwd_kernel<V, true>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, dw, db, M, d, rpb); \
+        hipLaunchKernelGGL((ln_bwd_kernel<V, true>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb); \
     else                                                                                               \
-        hipLaunchKernelGGL((ln_bwd_kernel<V, false>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, dw, db, M, d, rpb);
+        hipLaunchKernelGGL((ln_bwd_kernel<V, false>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb);
     switch (vpl) {
         case 1: LNB(1) break;
         case 2: LNB(2) break;
@@ -193,5 +198,6 @@ extern "C" int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, co
     }
 #undef LNB
     VLMO_CHECK_LAUNCH("vlmo_ln_bwd");
+    if (need_w) return reduce_partials(ws, grid, 2 * d, dw, d, db, stream);
     return 0;
 }

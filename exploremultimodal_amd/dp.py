@@ -1,0 +1,178 @@
+"""Data-parallel gradient averaging over RCCL (xGMI), overlapped with backward.
+
+Replaces the reference's DistributedDataParallel wrap
+(train/pretrain/multimodal.py:82-89, find_unused_parameters=True) and is the
+reduce half of its DeepSpeed ZeRO path (conf/ds_stage/l2.yaml).  One process
+per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm ("gloo" works for
+the CPU tests).
+
+Design (MI355X-first):
+  * parameters are grouped into flat buckets that follow the backward order:
+    one bucket per transformer Block (24-33 MB in bf16 for VLMo-Base) plus one for
+    embeddings / final norm / heads;
+  * the set of parameters that will receive a gradient in THIS pass is read off
+    the autograd graph in prepare(loss) (static expert routing => identical on
+    every rank), which is what DDP's find_unused_parameters does;
+  * when the last expected gradient of a bucket has been accumulated
+    (post-accumulate-grad hook) the bucket is packed into a flat comm buffer
+    (bf16 by default: half the bytes per link) and its all-reduce is issued on a
+    side stream while the backward of the next block runs;
+  * finish() waits for the side stream, unpacks (1/world scaling fused into the
+    unpack) and leaves p.grad as views of the flat fp32 bucket.
+`reduce_scatter=True` keeps only this rank's 1/W slice of every bucket reduced
+(ZeRO-2 gradient partition, ds_stage/l2.yaml) and exposes it as
+`bucket.shard`; the full gradient is then NOT written back.
+"""
+import re
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, name, params, device, comm_dtype, world):
+        self.name, self.params = name, params
+        self.offsets, n = [], 0
+        for p in params:
+            self.offsets.append(n)
+            n += p.numel()
+        self.numel = n
+        self.padded = ((n + world * 8 - 1) // (world * 8)) * (world * 8)
+        self.flat = torch.zeros(self.padded, dtype=torch.float32, device=device)
+        self.comm = self.flat if comm_dtype == torch.float32 else torch.zeros(
+            self.padded, dtype=comm_dtype, device=device)
+        self.shard = None
+        self.expected = 0
+        self.pending = 0
+        self.work = None
+        self.launched = False
+        self.used = []
+
+
+class GradReducer:
+    def __init__(self, module, process_group=None, comm_dtype=torch.bfloat16, reduce_scatter=False,
+                 broadcast_params=True):
+        self.pg = process_group if process_group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.pg)
+        self.rank = dist.get_rank(self.pg)
+        self.reduce_scatter = reduce_scatter
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('no trainable parameters')
+        self.device = params[0][1].device
+        self.on_gpu = self.device.type == 'cuda'
+        if not self.on_gpu:
+            comm_dtype = torch.float32          # gloo has no bf16 sum on every build
+        self.comm_dtype = comm_dtype
+        groups = {}
+        for n, p in params:
+            m = re.search(r'blocks\.(\d+)\.', n)
+            key = f'block{int(m.group(1)):03d}' if m else 'rest'
+            groups.setdefault(key, []).append(p)
+        # backward order: last block first, embeddings/rest last
+        order = sorted((k for k in groups if k != 'rest'), reverse=True) + (['rest'] if 'rest' in groups else [])
+        self.buckets = [_Bucket(k, groups[k], self.device, comm_dtype, self.world) for k in order]
+        self._of = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._of[p] = (b, i)
+                p.register_post_accumulate_grad_hook(self._hook)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self._armed = False
+        if broadcast_params and self.world > 1:
+            self.sync_params(module)
+
+    # ------------------------------------------------------------------ setup
+    def sync_params(self, module):
+        """rank 0's parameters and buffers everywhere (what DDP does at wrap time)."""
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=dist.get_global_rank(self.pg, 0) if self.pg is not dist.group.WORLD else 0,
+                               group=self.pg)
+
+    def bytes_per_step(self):
+        el = 2 if self.comm_dtype in (torch.bfloat16, torch.float16) else 4
+        return sum(b.padded for b in self.buckets) * el
+
+    # ------------------------------------------------------------ per-step API
+    def prepare(self, loss):
+        """Find the parameters this backward will touch (autograd graph walk) and arm the hooks."""
+        used = set()
+        seen, stack = set(), [loss.grad_fn] if loss.grad_fn is not None else []
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            v = getattr(fn, 'variable', None)
+            if v is not None and v in self._of:
+                used.add(v)
+            for nxt, _ in fn.next_functions:
+                stack.append(nxt)
+        for b in self.buckets:
+            b.used = [p in used for p in b.params]
+            b.expected = b.pending = sum(b.used)
+            b.work, b.launched = None, False
+        self._armed = True
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        b, _ = self._of[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        # pack: grads of this pass, zeros for parameters this pass did not touch
+        views = []
+        for p, off, u in zip(b.params, b.offsets, b.used):
+            v = b.comm[off:off + p.numel()]
+            if u and p.grad is not None:
+                v.copy_(p.grad.reshape(-1))
+            else:
+                v.zero_()
+            views.append(v)
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            ctxm = torch.cuda.stream(self.comm_stream)
+        else:
+            from contextlib import nullcontext
+            ctxm = nullcontext()
+        with ctxm:
+            if self.reduce_scatter:
+                n = b.padded // self.world
+                b.shard = torch.empty(n, dtype=b.comm.dtype, device=self.device)
+                b.work = dist.reduce_scatter_tensor(b.shard, b.comm, group=self.pg, async_op=True)
+            else:
+                b.work = dist.all_reduce(b.comm, group=self.pg, async_op=True)
+        b.launched = True
+
+    def finish(self):
+        """Wait for every bucket, scale by 1/world, hand the averaged gradients back."""
+        if not self._armed:
+            raise RuntimeError('GradReducer.finish() without prepare()')
+        self._armed = False
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            if b.expected == 0:
+                continue
+            if not b.launched:        # a hook did not fire (grad was None): flush what we have
+                self._launch(b)
+            b.work.wait()
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        for b in self.buckets:
+            if b.expected == 0:
+                continue
+            if self.reduce_scatter:
+                b.shard = b.shard.float().mul_(inv)
+                continue
+            if b.comm is b.flat:
+                b.flat.mul_(inv)
+            else:
+                b.flat.copy_(b.comm)                     # bf16 -> fp32 unpack
+                b.flat.mul_(inv)
+            for p, off, u in zip(b.params, b.offsets, b.used):
+                if u:
+                    p.grad = b.flat[off:off + p.numel()].view_as(p)

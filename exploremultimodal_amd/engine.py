@@ -178,7 +178,19 @@ class BlockFn(torch.autograd.Function):
         bf, f32 = torch.bfloat16, torch.float32
         sh, seed = meta.shadows, meta.seed
         dx2 = dx2.contiguous()
-        z = lambda *s: torch.zeros(s, dtype=f32, device=dev)
+        # every parameter gradient of this block lives in ONE zero-filled flat buffer (one memset)
+        nexp = len(meta.expert_ranges)
+        total = 6 * d + 3 * d * d + d * d + d + 3 * d + nexp * (2 * hid * d + hid + d)
+        flat = torch.zeros(total, dtype=f32, device=dev)
+        off = [0]
+
+        def z(*shape):
+            n = 1
+            for s_ in shape:
+                n *= s_
+            t = flat[off[0]:off[0] + n].view(*shape)
+            off[0] += n
+            return t
 
         dg1, dg2, dn1w, dn1b, dn2w, dn2b = z(d), z(d), z(d), z(d), z(d), z(d)
         dqkv_w, dproj_w, dproj_b = z(3 * d, d), z(d, d), z(d)

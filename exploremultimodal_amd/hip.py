@@ -17,8 +17,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libvlmo_hip.so')
 BF16, F16, F32 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
 
-_vp, _i32, _u32, _u64, _f32 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
-                               ctypes.c_uint64, ctypes.c_float)
+_vp, _i32, _u32, _u64, _f32, _i64 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
+                                     ctypes.c_uint64, ctypes.c_float, ctypes.c_int64)
 
 
 class Epilogue(ctypes.Structure):
@@ -34,13 +34,13 @@ _SIGS = {
                      ctypes.POINTER(Epilogue), _vp],
     'vlmo_gemm_tn': [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     'vlmo_ln_fwd': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
-    'vlmo_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    'vlmo_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp],
     'vlmo_attn_fwd': [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _f32,
                       _u64, _vp],
     'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f32,
                       _u32, _f32, _u64, _vp],
-    'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp],
-    'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp, _i64, _vp],
+    'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp],
     'vlmo_cast_weight': [_i32, _vp, _i32, _i32, _vp, _vp, _vp],
     'vlmo_patchify': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'vlmo_embed_img_finish': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _u32, _f32,
@@ -69,6 +69,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vlmo_last_error.restype = ctypes.c_char_p
         L.vlmo_abi_version.restype = ctypes.c_int
+        L.vlmo_reduce_ws_bytes.restype = ctypes.c_int64
+        L.vlmo_reduce_ws_bytes.argtypes = [_i32]
         for name, sig in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = sig
@@ -78,7 +80,7 @@ def lib():
 
 
 def exported_symbols():
-    return ['vlmo_last_error', 'vlmo_abi_version'] + list(_SIGS)
+    return ['vlmo_last_error', 'vlmo_abi_version', 'vlmo_reduce_ws_bytes'] + list(_SIGS)
 
 
 def _check(rc, name):
@@ -96,6 +98,19 @@ def _stream():
 
 def _dt(t):
     return {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}[t.dtype]
+
+
+_WS = {}
+
+
+def workspace(device, ncols):
+    """Persistent per-device scratch for the column-reducing kernels (stream-ordered reuse)."""
+    need = lib().vlmo_reduce_ws_bytes(ncols)
+    ws = _WS.get(device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(max(need, 1 << 23) // 4, dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
 
 
 def drop_params(p, training):
@@ -150,7 +165,8 @@ def ln_fwd(x, w, b, y, mean, rstd, rowmap, M, d, eps):
 
 def ln_bwd(dy, rowmap, x, w, mean, rstd, dres, dx, dw, db, M, d):
     rc = lib().vlmo_ln_bwd(_p(dy), int(dy.dtype == torch.float32), _p(rowmap), _p(x), _p(w),
-                           _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), M, d, _stream())
+                           _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), M, d, _p(ws := workspace(x.device, 2 * d)),
+                           ws.numel() * 4, _stream())
     _check(rc, 'vlmo_ln_bwd')
 
 
@@ -170,14 +186,16 @@ def attn_bwd(qkv, ctx, dctx, lse, seg, nseq, keymask, dqkv, heads, d, max_len, s
 
 
 def resid_bwd(dx, zd, gamma, row_scale, dz, dgamma, dbias, M, d, drop=(0, 1.0), seed=0):
+    ws = workspace(dx.device, 2 * d)
     rc = lib().vlmo_resid_bwd(_p(dx), _p(zd), _p(gamma), _p(row_scale), _p(dz), _p(dgamma),
                               _p(dbias), M, d, drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF,
-                              _stream())
+                              _p(ws), ws.numel() * 4, _stream())
     _check(rc, 'vlmo_resid_bwd')
 
 
 def colsum(x, out, M, N):
-    rc = lib().vlmo_colsum(_dt(x), _p(x), x.stride(0), _p(out), M, N, _stream())
+    ws = workspace(x.device, N)
+    rc = lib().vlmo_colsum(_dt(x), _p(x), x.stride(0), _p(out), M, N, _p(ws), ws.numel() * 4, _stream())
     _check(rc, 'vlmo_colsum')
 
 

@@ -80,10 +80,15 @@ int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, floa
 int vlmo_ln_fwd(const float* x, const float* w, const float* b, void* y, int out_f32,
                 float* mean, float* rstd, const int32_t* rowmap, int M, int d, float eps,
                 hipStream_t stream);
+/* Workspace (bytes) the column-reducing kernels below need for `ncols` reduced columns
+ * (ln_bwd and resid_bwd reduce 2*d columns, colsum N).  Caller-owned, reusable across calls
+ * on one stream. */
+int64_t vlmo_reduce_ws_bytes(int ncols);
+
 /* dx = dres + LN'(dy);  dw += sum dy*xhat;  db += sum dy  (dres may be NULL). */
 int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, const float* x, const float* w,
                 const float* mean, const float* rstd, const float* dres, float* dx, float* dw,
-                float* db, int M, int d, hipStream_t stream);
+                float* db, int M, int d, float* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* Fused softmax attention over packed rows (vlmo.py:79-95).
  * qkv [M, 3*d] (q | k | v, head-major inside each third), ctx [M, d].
@@ -102,10 +107,11 @@ int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const floa
  * dgamma += sum_m dx * row_scale * zd;  dbias += sum_m dz. */
 int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const float* row_scale,
                    void* dz, float* dgamma, float* dbias, int M, int d, uint32_t drop_thresh,
-                   float inv_keep, uint64_t seed, hipStream_t stream);
+                   float inv_keep, uint64_t seed, float* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* out[c] += sum_m x[m, c]  (bias gradients), x is bf16/f16 [M, ld]. */
-int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, int N, hipStream_t stream);
+int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, int N, float* ws,
+                int64_t ws_bytes, hipStream_t stream);
 
 /* fp32 -> bf16/f16 weight shadow copies: dst = cast(src), dstT = cast(src)^T (either may be NULL). */
 int vlmo_cast_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT,

@@ -144,3 +144,36 @@ def test_training_mode_dropout_is_unbiased_and_seeded():
     (a.float() ** 2).mean().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert (a - ref).abs().mean().item() < 0.5   # perturbed, not destroyed
+
+
+def test_grad_reducer_rccl_single_rank():
+    """The RCCL path (side stream, bf16 comm buffers, hooks fired from the autograd thread) at world
+    size 1: averaged gradients == local gradients up to one bf16 rounding."""
+    import torch.distributed as dist
+    from exploremultimodal_amd.dp import GradReducer
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        model, mc = build('mini')
+        model.train()
+        red = GradReducer(model)
+        batch = synth.synth_batch(mc, 4, seed=3)
+        kw = modes(mc, batch, 4)['vl']
+        x, _ = model.forward_features(**kw)
+        loss = x.float().square().mean()
+        loss.backward()
+        want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        for p in model.parameters():
+            p.grad = None
+        x, _ = model.forward_features(**kw)
+        loss = x.float().square().mean()
+        red.prepare(loss)
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(want)
+        for n in want:
+            assert torch.allclose(got[n], want[n], rtol=1e-2, atol=1e-2 * want[n].abs().max().item() + 1e-12), n
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,106 @@
+"""world_size-2 CPU (gloo) tests of the gradient reducer: averaged gradients equal the
+mean of the per-rank gradients, parameters that a pass does not touch keep grad=None
+(find_unused_parameters semantics of multimodal.py:82-89), reduce-scatter mode returns
+this rank's slice of the averaged flat bucket."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Linear(8, 16)
+        self.blocks = nn.ModuleList([nn.ModuleDict({'a': nn.Linear(16, 16), 'unused': nn.Linear(16, 16)})
+                                     for _ in range(3)])
+        self.norm = nn.LayerNorm(16)
+
+    def forward(self, x):
+        x = self.embed(x)
+        for b in self.blocks:
+            x = x + torch.tanh(b['a'](x))
+        return self.norm(x)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from exploremultimodal_amd.dp import GradReducer
+        torch.manual_seed(100 + rank)            # different init per rank: sync_params must fix it
+        model = Tiny()
+        red = GradReducer(model, reduce_scatter=(mode == 'rs'))
+        ref = Tiny()
+        ref.load_state_dict(model.state_dict())
+        w0 = [torch.zeros_like(p) for p in model.parameters()]
+        for w, p in zip(w0, model.parameters()):
+            w.copy_(p.detach())
+            dist.broadcast(w, src=0)
+        assert all(torch.equal(w, p.detach()) for w, p in zip(w0, model.parameters())), 'params not synced'
+        for step in range(2):
+            g = torch.Generator().manual_seed(7 + rank + 10 * step)
+            x = torch.randn(5, 8, generator=g)
+            for m in (model, ref):
+                for p in m.parameters():
+                    p.grad = None
+            loss = model(x).square().mean()
+            red.prepare(loss)
+            loss.backward()
+            red.finish()
+            ref(x).square().mean().backward()
+            for (n, p), pr in zip(model.named_parameters(), ref.parameters()):
+                if 'unused' in n:
+                    assert p.grad is None and pr.grad is None, n
+                    continue
+                want = pr.grad.clone()
+                dist.all_reduce(want)
+                want /= world
+                if mode == 'rs':
+                    continue
+                assert torch.allclose(p.grad, want, atol=1e-6), (n, (p.grad - want).abs().max())
+            if mode == 'rs':
+                for b in red.buckets:
+                    full = torch.zeros(b.padded)
+                    for p, off, u in zip(b.params, b.offsets, b.used):
+                        if u:
+                            pr = dict(ref.named_parameters())[
+                                [n for n, q_ in model.named_parameters() if q_ is p][0]]
+                            full[off:off + p.numel()] = pr.grad.reshape(-1)
+                    dist.all_reduce(full)
+                    full /= world
+                    n = b.padded // world
+                    assert torch.allclose(b.shard, full[rank * n:(rank + 1) * n], atol=1e-6), b.name
+        q.put((rank, 'ok'))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['allreduce', 'rs'])
+def test_grad_reducer_world2_gloo(mode):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
