@@ -125,14 +125,15 @@ class GradReducer:
 
     def _launch(self, b):
         # pack: grads of this pass, zeros for parameters this pass did not touch
-        views = []
+        b.had = []
         for p, off, u in zip(b.params, b.offsets, b.used):
             v = b.comm[off:off + p.numel()]
-            if u and p.grad is not None:
+            has = u and p.grad is not None
+            if has:
                 v.copy_(p.grad.reshape(-1))
             else:
-                v.zero_()
-            views.append(v)
+                v.zero_()       # e.g. img_mask_token in a pass without masked patches: backward gives None
+            b.had.append(has)
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             ctxm = torch.cuda.stream(self.comm_stream)
@@ -173,6 +174,6 @@ class GradReducer:
             else:
                 b.flat.copy_(b.comm)                     # bf16 -> fp32 unpack
                 b.flat.mul_(inv)
-            for p, off, u in zip(b.params, b.offsets, b.used):
-                if u:
+            for p, off, has in zip(b.params, b.offsets, b.had):
+                if has:
                     p.grad = b.flat[off:off + p.numel()].view_as(p)
