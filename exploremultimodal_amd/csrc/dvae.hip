@@ -1,0 +1,110 @@
+// Glue kernels of the dall_e dVAE encoder (dall_e/encoder.py:74-121) around the
+// implicit-GEMM convolutions of gemm.hip.  Activations are NHWC fp16 matrices
+// [B*H*W, C] (the reference runs this encoder in fp16 on GPU: dall_e/utils.py:37-42).
+#include "common.h"
+#include "vlmo_hip.h"
+
+namespace {
+
+// stem: x fp32 NCHW [B,C,H,W] -> fp16 [B*H*W, Kpad], column = c*kw*kw + ky*kw + kx (zero beyond C*kw*kw
+// and outside the image).  One thread = 8 consecutive columns (16-byte store).
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, f16* __restrict__ out, int B, int C,
+                                                     int H, int W, int kw, int Kpad, long total8) {
+    const int pad = (kw - 1) / 2, kk = kw * kw, kreal = C * kk, k8 = Kpad / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const long m = i / k8;
+        const int c0 = (int)(i % k8) * 8;
+        const int b = (int)(m / (H * W)), pix = (int)(m % (H * W));
+        const int y = pix / W, xx = pix % W;
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = c0 + j;
+            float val = 0.f;
+            if (col < kreal) {
+                const int c = col / kk, r = col % kk, ky = r / kw, kx = r % kw;
+                const int sy = y + ky - pad, sx = xx + kx - pad;
+                if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+                    val = x[(((size_t)b * C + c) * H + sy) * W + sx];
+            }
+            v[j] = (f16)val;
+        }
+        *(f16x8*)(out + m * Kpad + c0) = v;
+    }
+}
+
+// MaxPool2d(2) on NHWC (encoder.py:85,95,105) producing the raw pooled map and relu of it
+// (relu(maxpool(x)) == maxpool(relu(x))).  One thread = 8 channels.
+__global__ __launch_bounds__(256) void maxpool2_kernel(const f16* __restrict__ x, f16* __restrict__ raw,
+                                                       f16* __restrict__ rel, int B, int H, int W, int C, long total8) {
+    const int Ho = H / 2, Wo = W / 2, c8n = C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % c8n) * 8;
+        const long m = i / c8n;
+        const int b = (int)(m / (Ho * Wo)), pix = (int)(m % (Ho * Wo));
+        const int y = pix / Wo, xx = pix % Wo;
+        const f16* p = x + (((size_t)b * H + 2 * y) * W + 2 * xx) * C + c0;
+        const f16x8 a = *(const f16x8*)p, bb = *(const f16x8*)(p + C);
+        const f16x8 c = *(const f16x8*)(p + (size_t)W * C), d = *(const f16x8*)(p + (size_t)W * C + C);
+        f16x8 r, rr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = fmaxf(fmaxf((float)a[j], (float)bb[j]), fmaxf((float)c[j], (float)d[j]));
+            r[j] = (f16)v;
+            rr[j] = (f16)fmaxf(v, 0.f);
+        }
+        *(f16x8*)(raw + m * C + c0) = r;
+        if (rel) *(f16x8*)(rel + m * C + c0) = rr;
+    }
+}
+
+// partial [M, nchunk, {value f32, index i32}] -> ids int64 [M]; ties -> lowest index (torch.argmax)
+__global__ __launch_bounds__(256) void argmax_reduce_kernel(const float* __restrict__ part, int nchunk,
+                                                            int64_t* __restrict__ ids, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* p = part + (size_t)m * nchunk * 2;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = 0; c < nchunk; ++c) {
+        const float v = p[2 * c];
+        const int idx = ((const int*)p)[2 * c + 1];
+        if (v > best || (v == best && idx < bi)) {
+            best = v;
+            bi = idx;
+        }
+    }
+    ids[m] = bi;
+}
+
+}  // namespace
+
+extern "C" int vlmo_dvae_im2col(const float* x, void* out, int B, int C, int H, int W, int kw, int Kpad,
+                                hipStream_t stream) {
+    VLMO_CHECK_ARG(x && out, "vlmo_dvae_im2col: null pointer");
+    VLMO_CHECK_ARG(B > 0 && C > 0 && kw % 2 == 1 && Kpad % 64 == 0 && Kpad >= C * kw * kw, "vlmo_dvae_im2col: bad shape");
+    const long total8 = (long)B * H * W * (Kpad / 8);
+    const int grid = (int)((total8 + 255) / 256 < 65536 ? (total8 + 255) / 256 : 65536);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, x, (f16*)out, B, C, H, W, kw, Kpad, total8);
+    VLMO_CHECK_LAUNCH("vlmo_dvae_im2col");
+    return 0;
+}
+
+extern "C" int vlmo_maxpool2_nhwc(const void* x, void* raw, void* relu, int B, int H, int W, int C,
+                                  hipStream_t stream) {
+    VLMO_CHECK_ARG(x && raw, "vlmo_maxpool2_nhwc: null pointer");
+    VLMO_CHECK_ARG(B > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vlmo_maxpool2_nhwc: bad shape");
+    const long total8 = (long)B * (H / 2) * (W / 2) * (C / 8);
+    const int grid = (int)((total8 + 255) / 256 < 65536 ? (total8 + 255) / 256 : 65536);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid), dim3(256), 0, stream, (const f16*)x, (f16*)raw, (f16*)relu, B, H, W,
+                       C, total8);
+    VLMO_CHECK_LAUNCH("vlmo_maxpool2_nhwc");
+    return 0;
+}
+
+extern "C" int vlmo_argmax_reduce(const float* partial, int nchunk, int64_t* ids, int M, hipStream_t stream) {
+    VLMO_CHECK_ARG(partial && ids && M > 0 && nchunk > 0, "vlmo_argmax_reduce: bad arguments");
+    hipLaunchKernelGGL(argmax_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, partial, nchunk, ids, M);
+    VLMO_CHECK_LAUNCH("vlmo_argmax_reduce");
+    return 0;
+}

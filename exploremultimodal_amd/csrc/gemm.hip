@@ -19,13 +19,17 @@
 
 namespace {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3, EPI_F32 = 4 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3, EPI_F32 = 4, EPI_DUAL = 5, EPI_ARGMAX = 6 };
 
 struct GemmNT {
     const void* A;
     const void* B;
     int M, N, K, lda, ldb;
     VlmoEpilogue e;
+    // implicit-GEMM convolution over an NHWC activation matrix [B*H*W, Cin] (dVAE encoder):
+    // K = kw*kw*Cin, k-tile -> (tap, 64-channel chunk); taps outside the image read `zero`
+    int cH, cW, cCin, ckw;
+    const void* zero;
 };
 
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
@@ -90,6 +94,14 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4
         const float rs = e.row_scale ? e.row_scale[gm] : 1.f;
         const f32x4 r = *(const f32x4*)(e.resid + o);
         *(f32x4*)((float*)e.out + o) = r + g * v * rs;
+    } else if constexpr (EPI == EPI_DUAL) {
+        // dVAE EncoderBlock tail (dall_e/encoder.py:45-46): out = id + post_gain * res ; out2 = relu(out)
+        v *= e.beta;
+        if (e.resid) v += load4<T>((const T*)e.resid + o);
+        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+        if (e.out2)
+            store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f),
+                      fmaxf(v[3], 0.f));
     } else if constexpr (EPI == EPI_DGELU) {
         const f32x4 u = load4<T>((const T*)e.aux + (size_t)gm * e.ld2 + gn);
 #pragma unroll
@@ -112,7 +124,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
     typedef typename Elem<T>::v8 v8;
     constexpr int NW = WM * WN;
@@ -132,12 +144,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
 
     const T* a_src[NA];
     const T* b_src[NB];
+    int a_yx[NA];            // CONV: (y << 16) | x of the staged output pixel
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = (i * NW + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int gr = min(m0 + r, p.M - 1);
         a_src[i] = (const T*)p.A + (size_t)gr * p.lda + c * 8;
+        if constexpr (CONV) {
+            const int pix = gr % (p.cH * p.cW);
+            a_yx[i] = ((pix / p.cW) << 16) | (pix % p.cW);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -161,10 +178,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
     const int b_row_off = A_BYTES + (wn * (BN / WN) + l31) * 128;
 
     const int nk = p.K >> 6;
+    const int cpt = CONV ? (p.cCin >> 6) : 1, cpad = CONV ? (p.ckw - 1) / 2 : 0;
     auto stage = [&](int buf, int kt) {
         char* s = smem + buf * STAGE;
+        if constexpr (CONV) {
+            const int tap = kt / cpt, cc = kt - tap * cpt;
+            const int dy = tap / p.ckw - cpad, dx = tap % p.ckw - cpad;
+            const int delta = (dy * p.cW + dx) * p.cCin + cc * 64;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(a_src[i] + kt * 64, s + (i * NW + wave) * 1024);
+            for (int i = 0; i < NA; ++i) {
+                const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xFFFF) + dx;
+                const bool in = (unsigned)y < (unsigned)p.cH && (unsigned)x < (unsigned)p.cW;
+                const T* src = in ? a_src[i] + delta : (const T*)p.zero;
+                glds16(src, s + (i * NW + wave) * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(a_src[i] + kt * 64, s + (i * NW + wave) * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) glds16(b_src[i] + kt * 64, s + A_BYTES + (i * NW + wave) * 1024);
     };
@@ -211,7 +242,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
             const f32x4 v = *(const f32x4*)(ep + row * ROWF + rcol);
             const int gm = m0 + wm * (BM / WM) + i * 32 + row;
             const int gn = n0 + wn * (BN / WN) + rcol;
-            if (gm < p.M && gn < p.N) epilogue4<T, EPI>(p, gm, gn, v);
+            if constexpr (EPI == EPI_ARGMAX) {
+                // fused arg-max over the vocabulary (modeling_discrete_vae.py:246-248): per row, the best
+                // (value, index) of this wave's ROWF columns -> partial[gm][chunk]; logits never reach HBM
+                f32x4 vv = v;
+                if (p.e.bias && gn < p.N) vv += *(const f32x4*)(p.e.bias + gn);
+                float best = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gn + j < p.N && vv[j] > best) {
+                        best = vv[j];
+                        bi = gn + j;
+                    }
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) {
+                    const float ob = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ob > best || (ob == best && oi < bi)) {
+                        best = ob;
+                        bi = oi;
+                    }
+                }
+                if ((lane % LPR) == 0 && gm < p.M) {
+                    const int chunk = (n0 + wn * (BN / WN)) / ROWF;
+                    float* pv = (float*)p.e.out + ((size_t)gm * p.e.ldo + chunk) * 2;
+                    pv[0] = best;
+                    ((int*)pv)[1] = bi;
+                }
+            } else {
+                if (gm < p.M && gn < p.N) epilogue4<T, EPI>(p, gm, gn, v);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -340,14 +401,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV = false>
 int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr int LDS = 2 * (BM + BN) * 128;
     dim3 grid(tiles), block(WM * WN * 64);
 #define VLMO_LAUNCH_EPI(E)                                                                     \
     case E: {                                                                                  \
-        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E>;                                         \
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV>;                                         \
         if (LDS > 65536) {                                                                     \
             static bool attr_set = false;                                                      \
             if (!attr_set) {                                                                   \
@@ -357,15 +418,28 @@ int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
         }                                                                                      \
         hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                        \
     } break;
+    bool known = true;
     switch (epi) {
         VLMO_LAUNCH_EPI(EPI_BIAS)
-        VLMO_LAUNCH_EPI(EPI_BIAS_GELU)
-        VLMO_LAUNCH_EPI(EPI_RESID)
-        VLMO_LAUNCH_EPI(EPI_DGELU)
         VLMO_LAUNCH_EPI(EPI_F32)
+        VLMO_LAUNCH_EPI(EPI_DUAL)
         default:
-            vlmo_set_error("vlmo_gemm_nt: unknown epilogue %d", epi);
-            return -1;
+            if constexpr (!CONV) {
+                switch (epi) {
+                    VLMO_LAUNCH_EPI(EPI_BIAS_GELU)
+                    VLMO_LAUNCH_EPI(EPI_RESID)
+                    VLMO_LAUNCH_EPI(EPI_DGELU)
+                    VLMO_LAUNCH_EPI(EPI_ARGMAX)
+                    default:
+                        known = false;
+                }
+            } else {
+                known = false;
+            }
+    }
+    if (!known) {
+        vlmo_set_error("vlmo_gemm_nt/conv: unsupported epilogue %d", epi);
+        return -1;
     }
 #undef VLMO_LAUNCH_EPI
     VLMO_CHECK_LAUNCH("vlmo_gemm_nt");
@@ -381,12 +455,13 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     VLMO_CHECK_ARG(K % 64 == 0, "vlmo_gemm_nt: K=%d must be a multiple of 64", K);
     VLMO_CHECK_ARG(N % 4 == 0, "vlmo_gemm_nt: N=%d must be a multiple of 4", N);
     VLMO_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "vlmo_gemm_nt: bad lda/ldb %d/%d", lda, ldb);
-    VLMO_CHECK_ARG(e->out && e->ldo >= N && e->ldo % 4 == 0, "vlmo_gemm_nt: bad output / ldo");
+    VLMO_CHECK_ARG(e->out && (epi == EPI_ARGMAX || (e->ldo >= N && e->ldo % 4 == 0)), "vlmo_gemm_nt: bad output / ldo");
     VLMO_CHECK_ARG(epi != EPI_BIAS_GELU || (e->out2 && e->ld2 >= N), "vlmo_gemm_nt: gelu epilogue needs out2");
+    VLMO_CHECK_ARG(epi != EPI_ARGMAX || e->ldo >= (N + 63) / 64, "vlmo_gemm_nt: argmax partial buffer too narrow");
     VLMO_CHECK_ARG(epi != EPI_RESID || e->resid, "vlmo_gemm_nt: residual epilogue needs resid");
     VLMO_CHECK_ARG(epi != EPI_DGELU || (e->aux && e->ld2 >= N), "vlmo_gemm_nt: dgelu epilogue needs aux");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_nt: dtype must be bf16 or f16");
-    GemmNT p{A, B, M, N, K, lda, ldb, *e};
+    GemmNT p{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr};
     if (dtype == VLMO_F16) {
         if (tile == 1) return launch_nt<f16, 256, 128, 4, 2>(epi, p, stream);
         return launch_nt<f16, 128, 128, 2, 2>(epi, p, stream);
@@ -418,4 +493,21 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
         hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, 65536, stream, p);
     VLMO_CHECK_LAUNCH("vlmo_gemm_tn");
     return 0;
+}
+
+// 2-D convolution, stride 1, "same" zero padding (kw-1)/2, over an NHWC activation matrix
+// x [B*H*W, Cin] with weights w [Cout, kw*kw*Cin] (tap-major, channel-minor): dall_e/utils.py:37-48.
+extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H, int W, int Cin, int kw,
+                                const void* w, int Cout, const void* zero_page, const VlmoEpilogue* e,
+                                hipStream_t stream) {
+    VLMO_CHECK_ARG(x && w && e && zero_page, "vlmo_conv2d_nhwc: null pointer");
+    VLMO_CHECK_ARG(B > 0 && H > 0 && W > 0 && H < 32768 && W < 32768, "vlmo_conv2d_nhwc: bad geometry");
+    VLMO_CHECK_ARG(Cin % 64 == 0 && Cout % 4 == 0, "vlmo_conv2d_nhwc: Cin must be a multiple of 64 (got %d), Cout of 4", Cin);
+    VLMO_CHECK_ARG(kw >= 1 && kw % 2 == 1, "vlmo_conv2d_nhwc: kernel width must be odd (dall_e/utils.py:14)");
+    VLMO_CHECK_ARG(e->out && e->ldo >= Cout, "vlmo_conv2d_nhwc: bad output");
+    VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_conv2d_nhwc: dtype must be bf16 or f16");
+    const int K = kw * kw * Cin;
+    GemmNT p{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page};
+    if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
+    return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvlmo_hip.so')
 
 BF16, F16, F32 = 0, 1, 2
-EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32, EPI_DUAL, EPI_ARGMAX = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i32, _u32, _u64, _f32, _i64 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
                                      ctypes.c_uint64, ctypes.c_float, ctypes.c_int64)
@@ -49,6 +49,11 @@ _SIGS = {
                            _u64, _vp],
     'vlmo_embed_txt_fwd': [_vp] * 10 + [_i32, _i32, _i32, _f32, _u32, _f32, _u64, _vp],
     'vlmo_embed_txt_bwd': [_vp] * 11 + [_i32, _i32, _i32, _u32, _f32, _u64, _vp],
+    'vlmo_conv2d_nhwc': [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
+                         ctypes.POINTER(Epilogue), _vp],
+    'vlmo_dvae_im2col': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    'vlmo_maxpool2_nhwc': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'vlmo_argmax_reduce': [_vp, _i32, _vp, _i32, _vp],
 }
 
 _lib = None
@@ -242,3 +247,45 @@ def embed_txt_bwd(dx, ids, xhat, rstd, ln_w, dword, dpos, dbtype0, dln_w, dln_b,
                                   _p(dpos), _p(dbtype0), _p(dln_w), _p(dln_b), _p(dtype0), B, T, d,
                                   drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF, _stream())
     _check(rc, 'vlmo_embed_txt_bwd')
+
+
+# ------------------------------------------------------------------ dVAE encoder
+_ZERO = {}
+
+
+def zero_page(device):
+    z = _ZERO.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.float32, device=device)
+        _ZERO[device] = z
+    return z
+
+
+def conv2d_nhwc(epi, x, B, H, W, Cin, kw, w, Cout, out, *, out2=None, bias=None, resid=None, relu=False,
+                beta=0.0, ldo=None):
+    e = Epilogue(_p(out), _p(out2), _p(bias), None, _p(resid), None, None,
+                 ldo if ldo is not None else out.stride(0), out2.stride(0) if out2 is not None else 0,
+                 int(relu), 0, 1.0, beta, 0)
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = lib().vlmo_conv2d_nhwc(epi, _dt(x), _p(x), B, H, W, Cin, kw, _p(w), Cout, _p(zero_page(x.device)),
+                                ctypes.byref(e), _stream())
+    if ev is not None:
+        ev[1].record()
+        PROFILE.setdefault((f'conv_nt_kernel<epi={epi}>', 2 * B * H * W * Cout * kw * kw * Cin), []).append(ev)
+    _check(rc, 'vlmo_conv2d_nhwc')
+
+
+def dvae_im2col(x, out, kw, Kpad):
+    B, C, H, W = x.shape
+    _check(lib().vlmo_dvae_im2col(_p(x), _p(out), B, C, H, W, kw, Kpad, _stream()), 'vlmo_dvae_im2col')
+
+
+def maxpool2_nhwc(x, raw, relu, B, H, W, C):
+    _check(lib().vlmo_maxpool2_nhwc(_p(x), _p(raw), _p(relu), B, H, W, C, _stream()), 'vlmo_maxpool2_nhwc')
+
+
+def argmax_reduce(partial, nchunk, ids, M):
+    _check(lib().vlmo_argmax_reduce(_p(partial), nchunk, _p(ids), M, _stream()), 'vlmo_argmax_reduce')

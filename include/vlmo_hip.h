@@ -41,7 +41,10 @@ enum {
     VLMO_EPI_RESID = 2,     /* zd = dropout(acc + bias); out2[T] = zd;                        */
                             /* out[f32] = resid + gamma * zd * row_scale[m]                   */
     VLMO_EPI_DGELU = 3,     /* out[T]   = dropout_mask(acc) * gelu_erf'(aux[m,n])            */
-    VLMO_EPI_F32 = 4        /* out[f32] = acc + bias + beta * out                             */
+    VLMO_EPI_F32 = 4,       /* out[f32] = acc + bias + beta * out                             */
+    VLMO_EPI_DUAL = 5,      /* v = resid[T] + beta*(acc + bias); out[T] = v; out2[T] = relu(v)  */
+    VLMO_EPI_ARGMAX = 6     /* out = partial (max, argmax) of acc + bias per row and 64-column   */
+                            /* chunk: float/int32 pairs [M, ldo, 2]; finish with vlmo_argmax_reduce */
 };
 
 typedef struct VlmoEpilogue {
@@ -141,6 +144,24 @@ int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, c
                        const float* ln_w, float* dword, float* dpos, float* dbtype0, float* dln_w,
                        float* dln_b, float* dtype0, int B, int T, int d, uint32_t drop_thresh,
                        float inv_keep, uint64_t seed, hipStream_t stream);
+
+/* ---- dall_e dVAE encoder (dall_e/encoder.py:49-133), fp16 NHWC activations [B*H*W, C] ---- */
+
+/* Conv2d, stride 1, same padding (kw-1)/2 (dall_e/utils.py:37-48) as implicit GEMM:
+ * x [B*H*W, Cin], w [Cout, kw*kw*Cin] (tap-major, channel-minor), zero_page = >= 128 zero bytes.
+ * Epilogues: VLMO_EPI_BIAS (relu flag), VLMO_EPI_DUAL (EncoderBlock tail, encoder.py:45-46), VLMO_EPI_F32. */
+int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H, int W, int Cin, int kw,
+                     const void* w, int Cout, const void* zero_page, const VlmoEpilogue* e,
+                     hipStream_t stream);
+/* stem input: image f32 NCHW -> f16 [B*H*W, Kpad] patches, column = c*kw*kw + ky*kw + kx. */
+int vlmo_dvae_im2col(const float* x, void* out, int B, int C, int H, int W, int kw, int Kpad,
+                     hipStream_t stream);
+/* MaxPool2d(2) (encoder.py:85,95,105): raw pooled map + relu of it (relu may be NULL). */
+int vlmo_maxpool2_nhwc(const void* x, void* raw, void* relu, int B, int H, int W, int C,
+                       hipStream_t stream);
+/* final step of Dalle_VAE.get_codebook_indices (modeling_discrete_vae.py:246-248):
+ * partial [M, nchunk, 2] from VLMO_EPI_ARGMAX -> ids int64 [M] (first maximum wins). */
+int vlmo_argmax_reduce(const float* partial, int nchunk, int64_t* ids, int M, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -216,6 +216,7 @@ def main():
     run_backbone_case('backbone_debug', 'debug', B=2)
     run_backbone_case('backbone_base_b2', 'base', B=2, full_out=False)
     run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512)
+    run_dvae_case('dvae_small', B=2, res=32, n_hid=256, vocab_size=1024)
     run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False)
 
 
