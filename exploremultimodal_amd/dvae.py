@@ -243,12 +243,12 @@ class Dalle_VAE(nn.Module):
         raise NotImplementedError('the dall_e decoder is outside the pretraining hot path')
 
 
-def create_d_vae(weight_path, d_vae_type, image_size, device):
+def create_d_vae(weight_path, d_vae_type, image_size, device, vocab_size=8192):
     """objectives.py:595-607.  weight_path=None builds a randomly initialised encoder (synthetic runs)."""
     if d_vae_type == 'dall-e':
         vae = Dalle_VAE(image_size)
         if weight_path is None:
-            vae.encoder = Encoder(device=torch.device(device))
+            vae.encoder = Encoder(device=torch.device(device), vocab_size=vocab_size)
         else:
             vae.load_model(model_dir=weight_path, device=device)
         return vae

@@ -1,0 +1,135 @@
+"""Pretraining objectives of VlmoModule.forward (models/vlmo/objectives.py:12-314, 532-607):
+same function names, arguments and returned dict keys.  The backbone passes they trigger run
+on the HIP engine; the loss arithmetic on the gathered rows is stock torch.
+
+`compute_itm` draws its hard negatives with torch.multinomial like the reference
+(objectives.py:266-275) but in two batched calls instead of 2*B `.item()` host syncs; a caller
+that needs bit-reproducible negatives passes `batch['itm_neg_idx'] = (img_neg_idx, txt_neg_idx)`.
+"""
+import torch
+import torch.nn.functional as F
+
+from .dvae import create_d_vae  # noqa: F401  (objectives.create_d_vae in the reference)
+
+
+def compute_accuracy(logits, target):
+    """objectives.py:24-37."""
+    preds = logits.argmax(dim=-1)
+    preds = preds[target != -100]
+    target = target[target != -100]
+    if target.numel() == 0:
+        return torch.tensor(0, device=target.device), 0
+    assert preds.shape == target.shape
+    return (preds == target).float().mean(), target.numel()
+
+
+def compute_mlm(model, batch):
+    """objectives.py:40-78."""
+    has_img = any(['image' in k for k in batch.keys()])
+    infer = model.infer(batch, infer_mode='img-txt' if has_img else 'txt_only', mask_txt=True, mask_img=False)
+    txt_feats = infer['txt_feats']
+    mlm_labels = infer['txt_labels']
+    mask = (mlm_labels != -100).unsqueeze(-1).expand_as(txt_feats)
+    masked_txt_feats = txt_feats[mask].contiguous().view(-1, txt_feats.size(-1))
+    mlm_logits = model.mlm_head(masked_txt_feats)
+    mlm_labels = mlm_labels[mlm_labels != -100]
+    mlm_mean_acc, mlm_count = compute_accuracy(mlm_logits, mlm_labels)
+    if mlm_count > 0:
+        mlm_loss = F.cross_entropy(mlm_logits.view(-1, model.config.model.vocab_size), mlm_labels.view(-1),
+                                   ignore_index=-100)
+    else:
+        mlm_loss = 0.
+    return {'mlm_task_loss': mlm_loss, 'mlm_logits': mlm_logits, 'mlm_labels': mlm_labels,
+            'mlm_ids': infer['txt_ids'], 'mlm_mean_acc': mlm_mean_acc, 'mlm_count': mlm_count}
+
+
+def compute_itc(model, batch):
+    """objectives.py:81-236, naive in-batch branch (global_reduce / momentum / queue are off in
+    conf/train/pretrain_mum.yaml:39-42 and out of scope)."""
+    with torch.no_grad():
+        model.itc_temp.data = torch.clamp(model.itc_temp.data, 0, 4.6052)
+    temp = model.itc_temp.exp()
+    if model.config.train.global_reduce or model.transformer_m is not None:
+        raise NotImplementedError('global_reduce / momentum ITC branches are out of scope (SURVEY.md 8f)')
+    img_infer = model.infer(batch, infer_mode='img_only')
+    txt_infer = model.infer(batch, infer_mode='txt_only')
+    i_feat = model.itc_head(img_infer['co_feats'][:, 0], 'v')
+    t_feat = model.itc_head(txt_infer['co_feats'][:, 0], 'l')
+    bs = i_feat.size(0)
+    sim_targets = torch.arange(bs, device=i_feat.device)
+    sim_i2t = i_feat @ t_feat.t() * temp
+    sim_t2i = sim_i2t.t()
+    i2t_loss = F.cross_entropy(sim_i2t, sim_targets)
+    t2i_loss = F.cross_entropy(sim_t2i, sim_targets)
+    itc_i2t_mean_acc, itc_i2t_count = compute_accuracy(sim_i2t[:, :bs], sim_targets)
+    itc_t2i_mean_acc, itc_t2i_count = compute_accuracy(sim_t2i[:, :bs], sim_targets)
+    return {'itc_task_loss': (i2t_loss + t2i_loss) / 2, 'i2t_Loss': i2t_loss, 't2i_Loss': t2i_loss,
+            'sim_i2t': sim_i2t, 'sim_t2i': sim_t2i, 'itc_temp': temp.data,
+            'itc_i2t_mean_acc': itc_i2t_mean_acc, 'itc_i2t_count': itc_i2t_count,
+            'itc_t2i_mean_acc': itc_t2i_mean_acc, 'itc_t2i_count': itc_t2i_count}
+
+
+def compute_itm(model, batch, sim_dict=None):
+    """objectives.py:239-314."""
+    txt_ids, txt_mask, img = batch['text_ids'], batch['text_mask'], batch['image']
+    bs = img.size(0)
+    output_pos = model.infer(batch, infer_mode='img-txt')
+    with torch.no_grad():
+        if batch.get('itm_neg_idx') is not None:
+            img_neg_idx, txt_neg_idx = batch['itm_neg_idx']
+        else:
+            if sim_dict is not None:
+                weights_i2t = F.softmax(sim_dict['sim_i2t'][:, :bs].float(), dim=1) + 1e-5
+                weights_t2i = F.softmax(sim_dict['sim_t2i'][:, :bs].float(), dim=1) + 1e-5
+            else:
+                weights_i2t = F.softmax(torch.randn([bs, bs], device=img.device), dim=1) + 1e-5
+                weights_t2i = F.softmax(torch.randn([bs, bs], device=img.device), dim=1) + 1e-5
+            weights_i2t.fill_diagonal_(0)
+            weights_t2i.fill_diagonal_(0)
+            img_neg_idx = torch.multinomial(weights_t2i, 1).squeeze(1)     # one draw per row, no host sync
+            txt_neg_idx = torch.multinomial(weights_i2t, 1).squeeze(1)
+    img_neg = img[img_neg_idx]
+    txt_ids_all = torch.cat([txt_ids, txt_ids[txt_neg_idx]], dim=0)
+    txt_mask_all = torch.cat([txt_mask, txt_mask[txt_neg_idx]], dim=0)
+    img_all = torch.cat([img_neg, img], dim=0)
+    itm_neg_batch = {'text_ids': txt_ids_all, 'text_mask': txt_mask_all, 'image': img_all}
+    output_neg = model.infer(itm_neg_batch, infer_mode='img-txt')
+    cls_feat = torch.cat([output_pos['cls_feats'], output_neg['cls_feats']], dim=0)
+    itm_logits = model.itm_head(cls_feat)
+    itm_labels = torch.cat([torch.ones(1 * bs, dtype=torch.long, device=itm_logits.device),
+                            torch.zeros(2 * bs, dtype=torch.long, device=itm_logits.device)], dim=0)
+    itm_loss = F.cross_entropy(itm_logits, itm_labels)
+    itm_mean_acc, itm_count = compute_accuracy(itm_logits, itm_labels)
+    return {'itm_task_loss': itm_loss, 'itm_logits': itm_logits, 'itm_labels': itm_labels,
+            'itm_mean_acc': itm_mean_acc, 'itm_count': itm_count}
+
+
+def compute_mim(module, batch):
+    """objectives.py:532-592."""
+    with torch.no_grad():
+        input_ids = module.d_vae.get_codebook_indices(batch['image4dalle']).flatten(1)
+        batch['image_bool_masked_pos'] = batch['image_bool_masked_pos'].flatten(1).to(torch.bool)
+        bool_masked_pos = batch['image_bool_masked_pos']
+        mim_labels = input_ids[bool_masked_pos]
+    pos = module.config.train.mim_head_pos
+    if pos in ['img']:
+        infer = module.infer(batch, infer_mode='img_only', mask_txt=False, mask_img=True)
+    elif pos in ['mum']:
+        infer = module.infer(batch, infer_mode='img-txt', mask_txt=False, mask_img=True)
+    elif pos in ['fusion']:
+        img_feats = module.transformer.forward_interval(
+            x=batch['image'], attn_masks=None, route='v', need_embed=True, bool_masked_pos=bool_masked_pos,
+            in_layer=0, out_layer=module.transformer.fusion_layer, need_norm=True)
+        infer = {'img_feats': img_feats}
+    else:
+        raise KeyError(f'unknown mim_head_pos {pos!r}')
+    patch_x = infer['img_feats'][:, 1:]
+    masked_patch_x = patch_x[bool_masked_pos].contiguous()
+    mim_logits = module.mim_head(masked_patch_x)
+    mim_mean_acc, mim_count = compute_accuracy(mim_logits, mim_labels)
+    if mim_count > 0:
+        mim_loss = F.cross_entropy(mim_logits.view(-1, module.config.model.img_vocab_size), mim_labels.view(-1))
+    else:
+        mim_loss = 0.
+    return {'mim_task_loss': mim_loss, 'mim_logits': mim_logits, 'mim_labels': mim_labels,
+            'mim_mean_acc': mim_mean_acc, 'mim_count': mim_count}

@@ -1,0 +1,208 @@
+"""Host-side mirror of VlmoModule (models/vlmo/vlmo_module.py:14-442): same constructor
+(attribute-style config), parameter names, `infer` / `forward` / `load_from_ckpt` /
+`no_weight_decay` contracts.  Pretraining losses [mlm, mim, itc, itm]; the downstream
+(vqa / nlvr2 / irtr / mpp), EMA and negative-queue branches raise NotImplementedError
+(out of scope, off in conf/train/pretrain_mum.yaml)."""
+from collections import defaultdict
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import objectives
+from .heads import ITCHead, ITMHead, MIMHead, MLMHead
+from .vlmo import VLMO, LayerNorm
+
+
+class VlmoModule(nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        model_cfg = config.model
+        norm_layer = partial(LayerNorm, eps=1e-12, export='fused' not in model_cfg.norm_layer)
+        self.transformer = VLMO(
+            img_size=model_cfg.img_size, patch_size=model_cfg.patch_size, in_chans=model_cfg.in_chans,
+            num_classes=model_cfg.num_classes, embed_dim=model_cfg.embed_dim, depth=model_cfg.depth,
+            num_heads=model_cfg.num_heads, mlp_ratio=model_cfg.mlp_ratio, qkv_bias=model_cfg.qkv_bias,
+            qk_scale=None, drop_rate=model_cfg.drop_rate, attn_drop_rate=model_cfg.attn_drop_rate,
+            drop_path_rate=model_cfg.drop_path_rate, norm_layer=norm_layer, init_values=model_cfg.init_values,
+            vocab_size=model_cfg.vocab_size, max_text_len=model_cfg.max_text_len,
+            fusion_layer=model_cfg.fusion_layer)
+        self._freeze_params()
+
+        self.loss_names = config.train.loss_names
+        hs = model_cfg.embed_dim
+        for unsupported in ('mpp', 'vqa', 'nlvr2', 'irtr', 'refcoco'):
+            if unsupported in self.loss_names:
+                raise NotImplementedError(f'loss {unsupported!r} belongs to a downstream phase outside the '
+                                          'pretraining hot path')
+        if 'mlm' in self.loss_names:
+            self.mlm_head = MLMHead(self.transformer.bert_config,
+                                    weight=self.transformer.txt_embeddings.word_embeddings.weight)
+            self.mlm_head.apply(self.transformer._init_weights)
+        if 'itc' in self.loss_names:
+            self.itc_head = ITCHead(hs, model_cfg.itc_dim)
+            self.itc_head.apply(self.transformer._init_weights)
+            self.itc_temp = nn.Parameter(torch.ones([]) * np.log(1 / model_cfg.itc_temp))
+        if 'itm' in self.loss_names:
+            self.itm_head = ITMHead(hs)
+            self.itm_head.apply(self.transformer._init_weights)
+        if 'mim' in self.loss_names:
+            self.d_vae = objectives.create_d_vae(weight_path=config.train.discrete_vae_weight_path,
+                                                 d_vae_type=config.train.discrete_vae_type, device='cpu',
+                                                 image_size=model_cfg.img_size // 2,
+                                                 vocab_size=model_cfg.img_vocab_size)
+            for p in self.d_vae.parameters():
+                p.requires_grad = False
+            self.mim_head = MIMHead(hs, model_cfg.img_vocab_size)
+            self.mim_head.apply(self.transformer._init_weights)
+
+        self.transformer_m = None
+        if getattr(self.config, 'vlmo_ema', False):
+            raise NotImplementedError('vlmo_ema (momentum twin) is out of scope; config.yaml:136 default is off')
+        if hasattr(config.train, 'neg_queue') and config.train.neg_queue:
+            raise NotImplementedError('neg_queue is out of scope; pretrain_mum.yaml:40 default is off')
+        self.q_size = 0
+        self.img_queue, self.txt_queue = None, None
+
+    def _freeze_params(self):
+        """vlmo_module.py:148-167."""
+        if self.config.train.phase in ['pretrain_txt']:
+            for b in self.transformer.blocks:
+                del b.mlp['vl']
+                if self.config.train.fixed_attn:
+                    b.gamma_1.requires_grad = False
+                    b.gamma_2.requires_grad = False
+                    for p in b.attn.parameters():
+                        p.requires_grad = False
+                    for p in b.norm1.parameters():
+                        p.requires_grad = False
+                    for p in b.norm2.parameters():
+                        p.requires_grad = False
+            for p in self.transformer.norm.parameters():
+                p.requires_grad = False
+        elif self.config.train.phase in ['pretrain_mum', 'finetune_vqa']:
+            for b in self.transformer.blocks[:self.transformer.fusion_layer]:
+                del b.mlp['vl']
+
+    def _adjust_downstream_params(self):
+        """vlmo_module.py:169-185: only touches nlvr2 / irtr heads, which this module never builds."""
+
+    # ------------------------------------------------------------- checkpoints
+    def interpolate_pos_embedding(self, state_dict):
+        """vlmo_module.py:187-232."""
+        for pos_embed_key in ['pos_embed', 'transformer.pos_embed']:
+            if pos_embed_key in state_dict:
+                pos_embed_ckpt = state_dict[pos_embed_key]
+                embedding_size = pos_embed_ckpt.shape[-1]
+                num_patches = self.transformer.patch_embed.num_patches
+                num_extra_tokens = self.transformer.pos_embed.shape[-2] - num_patches
+                orig_size = int((pos_embed_ckpt.shape[-2] - num_extra_tokens) ** 0.5)
+                new_size = int(num_patches ** 0.5)
+                if orig_size != new_size:
+                    extra_tokens = pos_embed_ckpt[:, :num_extra_tokens]
+                    pos_tokens = pos_embed_ckpt[:, num_extra_tokens:]
+                    pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
+                    pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size),
+                                                                 mode='bicubic', align_corners=False)
+                    pos_tokens = pos_tokens.permute(0, 2, 3, 1).flatten(1, 2)
+                    state_dict[pos_embed_key] = torch.cat((extra_tokens, pos_tokens), dim=1)
+        k = 'transformer.txt_embeddings.position_embeddings.weight'
+        if k in state_dict:
+            state_dict[k] = state_dict[k][:self.transformer.max_text_len, :]
+        state_dict.pop('transformer.txt_embeddings.position_ids', None)   # non-persistent buffer upstream
+        return state_dict
+
+    def _load_vlmo(self, state_dict):
+        for k in list(state_dict.keys()):
+            for old, new in (('.mlp.v_mlp', '.mlp.v'), ('.mlp.l_mlp', '.mlp.l'), ('.mlp.vl_mlp', '.mlp.vl')):
+                if old in k:
+                    state_dict[k.replace(old, new)] = state_dict.pop(k)
+                    break
+        matching = self.load_state_dict(state_dict, strict=False)
+        self._adjust_downstream_params()
+        return matching
+
+    def _load_beit(self, state_dict):
+        for k in list(state_dict.keys()):
+            nk = k
+            if 'mlp' in nk:
+                nk = nk.replace('.mlp', '.mlp.v')
+            if 'mask_token' in nk:
+                nk = nk.replace('mask_token', 'img_mask_token')
+            elif 'cls_token' in nk:
+                nk = nk.replace('cls_token', 'img_cls_token')
+            if 'lm_head' in nk:
+                nk = nk.replace('lm_head', 'fc')
+            if nk != k:
+                state_dict[nk] = state_dict.pop(k)
+        if 'mim' in self.loss_names:
+            self.mim_head.load_state_dict(state_dict, strict=False)
+        matching = self.transformer.load_state_dict(state_dict, strict=False)
+        self._adjust_downstream_params()
+        return matching
+
+    def load_from_ckpt(self, state_dict):
+        """vlmo_module.py:300-319 -> (matching, is_beit)."""
+        state_dict = self.interpolate_pos_embedding(state_dict)
+        is_beit = not any(('.mlp.v' in k or '.mlp.l' in k or '.mlp.vl' in k) for k in state_dict)
+        matching = (self._load_beit if is_beit else self._load_vlmo)(state_dict)
+        return matching, is_beit
+
+    # ------------------------------------------------------------------ infer
+    def infer(self, batch, infer_mode='img-txt', mask_txt=False, mask_img=False, image_token_type_idx=1,
+              momentum_mode=False):
+        """vlmo_module.py:321-393."""
+        assert infer_mode in ['img_only', 'txt_only', 'img-txt']
+        if momentum_mode:
+            assert self.transformer_m is not None
+        transformer = self.transformer
+        img, img_attn_masks, bool_masked_pos = None, None, None
+        txt_ids, txt_labels, txt_attn_masks = None, None, None
+        if 'img' in infer_mode:
+            imgkey = f'image_{image_token_type_idx - 1}' if f'image_{image_token_type_idx - 1}' in batch else 'image'
+            img = batch[imgkey]
+            B = img.size(0)
+            img_attn_masks = torch.ones([B, transformer.patch_embed.num_patches + 1], dtype=torch.int64,
+                                        device=img.device)
+            bool_masked_pos = batch['image_bool_masked_pos'] if mask_img else None
+        if 'txt' in infer_mode:
+            do_mlm = '_mlm' if mask_txt else ''
+            txt_ids = batch[f'text_ids{do_mlm}']
+            txt_labels = batch[f'text_labels{do_mlm}'] if mask_txt else None
+            txt_attn_masks = batch['text_mask']
+        co_feats, _ = transformer.forward_features(img=img, txt=txt_ids, img_attn_masks=img_attn_masks,
+                                                   txt_attn_masks=txt_attn_masks, bool_masked_pos=bool_masked_pos,
+                                                   fusion_layer=None)
+        if txt_ids is not None:
+            txt_feats, img_feats = (co_feats[:, :transformer.max_text_len], co_feats[:, transformer.max_text_len:])
+        else:
+            txt_feats, img_feats = None, co_feats
+        cls_feats = transformer.pooler(co_feats)
+        return {'txt_feats': txt_feats, 'img_feats': img_feats, 'co_feats': co_feats, 'cls_feats': cls_feats,
+                'img_masks': img_attn_masks, 'img_bool_masked_pos': bool_masked_pos, 'txt_labels': txt_labels,
+                'txt_ids': txt_ids, 'txt_masks': txt_attn_masks}
+
+    def forward(self, batch):
+        """vlmo_module.py:395-436."""
+        batch = defaultdict(lambda: None, batch)
+        ret = dict()
+        if len(self.loss_names) == 0:
+            ret.update(self.infer(batch))
+            return ret
+        if 'mlm' in self.loss_names:
+            ret.update(objectives.compute_mlm(self, batch))
+        if 'mim' in self.loss_names:
+            ret.update(objectives.compute_mim(self, batch))
+        if 'itc' in self.loss_names:
+            ret.update(objectives.compute_itc(self, batch))
+        if 'itm' in self.loss_names:
+            itc_ret = ret if 'itc' in self.loss_names else None
+            ret.update(objectives.compute_itm(self, batch, itc_ret))
+        return ret
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'itc_temp', 'transformer.pos_embed', 'transformer.img_cls_token'}

@@ -205,6 +205,70 @@ def run_dvae_case(name, B, res, seed=0, full_logits=True, **enc_kw):
     print(f'wrote {name}.npz')
 
 
+def run_module_case(name, preset, B, seed=0):
+    """Full VlmoModule.forward(batch) with [mlm, mim, itc, itm] (vlmo_module.py:395-436).
+    Two call-argument level accommodations, arithmetic untouched:
+    the dVAE pickles are absent, so objectives.create_d_vae is pointed at a Dalle_VAE whose
+    encoder is a seeded dall_e Encoder with synthetic weights; torch.multinomial is wrapped to
+    RECORD the hard-negative indices compute_itm draws (objectives.py:268-275)."""
+    from oracle import synth
+    import models.vlmo.objectives as ref_obj
+    from models.build import build_model
+    from models.modeling_discrete_vae import Dalle_VAE
+    from dall_e.encoder import Encoder
+    losses = ['mlm', 'mim', 'itc', 'itm']
+    cfg = synth.make_config(preset, loss_names=losses)
+    mc = cfg.model
+    mc.mlp_ratio = int(mc.mlp_ratio)
+    enc_kw = dict(n_hid=256, vocab_size=mc.img_vocab_size)
+
+    def fake_create(weight_path, d_vae_type, image_size, device):
+        vae = Dalle_VAE(image_size)
+        vae.encoder = Encoder(**enc_kw).eval()
+        vae.encoder.load_state_dict(synth.synth_dvae_state_dict(seed, **enc_kw), strict=True)
+        return vae
+    ref_obj.create_d_vae = fake_create
+    model = build_model(cfg).eval()
+    sd = {'transformer.' + k: v for k, v in synth.synth_backbone_state_dict(mc, seed).items()}
+    sd.update(synth.synth_head_state_dict(mc, seed, losses))
+    r = model.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys, r.unexpected_keys
+    assert all(k.startswith('d_vae.') or k == 'mlm_head.decoder.weight' for k in r.missing_keys), r.missing_keys
+    batch = synth.synth_batch(mc, B, seed=1234)
+    drawn = []
+    real_multinomial = torch.multinomial
+
+    def rec_multinomial(w, n, *a, **k):
+        out = real_multinomial(w, n, *a, **k)
+        drawn.append(int(out.item()))
+        return out
+    torch.multinomial = rec_multinomial
+    try:
+        torch.manual_seed(1)
+        ret = model(dict(batch))
+    finally:
+        torch.multinomial = real_multinomial
+    rec = {'itm_img_neg_idx': np.array(drawn[:B]), 'itm_txt_neg_idx': np.array(drawn[B:2 * B])}
+    total = 0
+    for k, v in ret.items():
+        if torch.is_tensor(v):
+            rec['ret.' + k] = v.detach().float().numpy() if v.is_floating_point() else v.detach().numpy()
+        else:
+            rec['ret.' + k] = np.float64(v)
+        if 'task_loss' in k:
+            total = total + v
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None and not k.startswith('d_vae.'):
+            rec['grad_norm.' + k] = np.float64(p.grad.double().norm().item())
+            rec['grad_probe.' + k] = np.float64((p.grad.double() * grad_probe(k, p.shape).double()).sum().item())
+    rec['meta.B'] = np.int64(B)
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **rec)
+    print(f'wrote {name}.npz with {len(rec)} arrays; losses',
+          {k: float(v) for k, v in ret.items() if 'task_loss' in k})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -215,6 +279,7 @@ def main():
     run_backbone_case('backbone_small', 'small', B=2)
     run_backbone_case('backbone_debug', 'debug', B=2)
     run_backbone_case('backbone_base_b2', 'base', B=2, full_out=False)
+    run_module_case('module_mini', 'mini', B=4)
     run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512)
     run_dvae_case('dvae_small', B=2, res=32, n_hid=256, vocab_size=1024)
     run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False)
