@@ -16,6 +16,7 @@
 // math fused in.
 #include "common.h"
 #include "vlmo_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,6 +31,7 @@ struct GemmNT {
     // K = kw*kw*Cin, k-tile -> (tap, 64-channel chunk); taps outside the image read `zero`
     int cH, cW, cCin, ckw;
     const void* zero;
+    int group_m;     // L2 tile swizzle: row-tiles per group
 };
 
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
@@ -51,14 +53,15 @@ template <> __device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
-// One call = 4 consecutive output columns (gn..gn+3) of row gm.
+// Epilogue math for 4 consecutive output columns (gn..gn+3) of row gm.  Everything that has to come
+// from global memory is passed in (bias/gamma: loaded once per tile; `ext` = residual / pre-activation
+// row segment and `rs` = drop-path scale: loaded for a whole pass BEFORE any math so the ~1-2 us
+// global latencies overlap instead of serialising load -> math -> store per row group).
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4 v) {
+__device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4 v, f32x4 bias4, f32x4 gamma4,
+                                          f32x4 ext, float rs) {
     const VlmoEpilogue& e = p.e;
-    if (e.bias) {
-        const f32x4 b = *(const f32x4*)(e.bias + gn);
-        v += b;
-    }
+    v += bias4;
     const size_t o = (size_t)gm * e.ldo + gn;
     if constexpr (EPI == EPI_BIAS) {
         if (e.relu) {
@@ -67,12 +70,10 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4
         }
         store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_F32) {
-        float* out = (float*)e.out + o;
-        if (e.beta != 0.f) v += e.beta * (*(const f32x4*)out);
-        *(f32x4*)out = v;
+        if (e.beta != 0.f) v += e.beta * ext;
+        *(f32x4*)((float*)e.out + o) = v;
     } else if constexpr (EPI == EPI_BIAS_GELU) {
         store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);   // u (pre-activation)
-        // GELU on the value the backward will see (u rounded to T)
         f32x4 h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = gelu_erf(v[j]);
@@ -89,29 +90,41 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4
             for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
         }
         if (e.out2) store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, v[0], v[1], v[2], v[3]);
-        f32x4 g = {1.f, 1.f, 1.f, 1.f};
-        if (e.gamma) g = *(const f32x4*)(e.gamma + gn);
-        const float rs = e.row_scale ? e.row_scale[gm] : 1.f;
-        const f32x4 r = *(const f32x4*)(e.resid + o);
-        *(f32x4*)((float*)e.out + o) = r + g * v * rs;
+        *(f32x4*)((float*)e.out + o) = ext + gamma4 * v * rs;
     } else if constexpr (EPI == EPI_DUAL) {
         // dVAE EncoderBlock tail (dall_e/encoder.py:45-46): out = id + post_gain * res ; out2 = relu(out)
-        v *= e.beta;
-        if (e.resid) v += load4<T>((const T*)e.resid + o);
+        v = v * e.beta + ext;
         store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
         if (e.out2)
             store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f),
                       fmaxf(v[3], 0.f));
     } else if constexpr (EPI == EPI_DGELU) {
-        const f32x4 u = load4<T>((const T*)e.aux + (size_t)gm * e.ld2 + gn);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(ext[j]);
         if (e.drop_thresh) {
             const uint64_t bits = drop_bits4(e.seed, ((uint64_t)gm * p.N + gn) >> 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
         }
         store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+    }
+}
+
+// the row segment an epilogue needs from global memory besides the accumulators (clamped row: always valid)
+template <typename T, int EPI>
+__device__ __forceinline__ f32x4 epilogue_ext(const GemmNT& p, int gmc, int gnc) {
+    const VlmoEpilogue& e = p.e;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_RESID) {
+        return *(const f32x4*)(e.resid + (size_t)gmc * e.ldo + gnc);
+    } else if constexpr (EPI == EPI_DGELU) {
+        return load4<T>((const T*)e.aux + (size_t)gmc * e.ld2 + gnc);
+    } else if constexpr (EPI == EPI_DUAL) {
+        return e.resid ? load4<T>((const T*)e.resid + (size_t)gmc * e.ldo + gnc) : z;
+    } else if constexpr (EPI == EPI_F32) {
+        return e.beta != 0.f ? *(const f32x4*)((const float*)e.out + (size_t)gmc * e.ldo + gnc) : z;
+    } else {
+        return z;
     }
 }
 
@@ -124,31 +137,45 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
+// K-tile depth BK (64 or 32): BK=32 halves the LDS ring (32 KB for 128x128) so four workgroups
+// fit a CU instead of two (more latency hiding, phases of co-resident workgroups decorrelate).
+template <int BK> __device__ __forceinline__ int nt_swz(int row) {
+    return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK>
+__global__ __launch_bounds__(WM * WN * 64, (BK == 32 && WM * WN == 4) ? 4 : 2) void gemm_nt_kernel(const GemmNT p) {
     typedef typename Elem<T>::v8 v8;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+    constexpr int ROWB = BK * 2, CPR = ROWB / 16, SRPI = 1024 / ROWB, KS = BK / 16;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM / SRPI / NW, NB = BN / SRPI / NW;
+    static_assert(BM % (SRPI * NW) == 0 && BN % (SRPI * NW) == 0, "tile/wave mismatch");
     static_assert(NW * 32 * TN * 32 * 4 <= 2 * STAGE, "epilogue LDS must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    // grouped order: the ~64 tiles an XCD works on at once form a compact group_m x (64/group_m)
+    // block, so their A row-panels AND B column-panels together fit the XCD's 4 MiB L2
+    const int gm_ = p.group_m > 0 ? p.group_m : 1;
+    const int per_group = gm_ * tiles_n;
+    const int first_m = (lid / per_group) * gm_;
+    const int gsz = min(tiles_m - first_m, gm_);
+    const int in_g = lid % per_group;
+    const int m0 = (first_m + in_g % gsz) * BM, n0 = (in_g / gsz) * BN;
 
     const T* a_src[NA];
     const T* b_src[NB];
     int a_yx[NA];            // CONV: (y << 16) | x of the staged output pixel
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int r = (i * NW + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (i * NW + wave) * SRPI + lane / CPR;
+        const int c = (lane % CPR) ^ nt_swz<BK>(r);
         const int gr = min(m0 + r, p.M - 1);
         a_src[i] = (const T*)p.A + (size_t)gr * p.lda + c * 8;
         if constexpr (CONV) {
@@ -158,8 +185,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int r = (i * NW + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (i * NW + wave) * SRPI + lane / CPR;
+        const int c = (lane % CPR) ^ nt_swz<BK>(r);
         const int gr = min(n0 + r, p.N - 1);
         b_src[i] = (const T*)p.B + (size_t)gr * p.ldb + c * 8;
     }
@@ -173,18 +200,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
     const int l31 = lane & 31, h = lane >> 5;
-    const int swz = (l31 >> 1) & 7;
-    const int a_row_off = (wm * (BM / WM) + l31) * 128;
-    const int b_row_off = A_BYTES + (wn * (BN / WN) + l31) * 128;
+    const int swz = nt_swz<BK>(l31);
+    const int a_row_off = (wm * (BM / WM) + l31) * ROWB;
+    const int b_row_off = A_BYTES + (wn * (BN / WN) + l31) * ROWB;
 
-    const int nk = p.K >> 6;
-    const int cpt = CONV ? (p.cCin >> 6) : 1, cpad = CONV ? (p.ckw - 1) / 2 : 0;
+    const int nk = p.K / BK;
+    const int cpt = CONV ? (p.cCin / BK) : 1, cpad = CONV ? (p.ckw - 1) / 2 : 0;
     auto stage = [&](int buf, int kt) {
         char* s = smem + buf * STAGE;
         if constexpr (CONV) {
             const int tap = kt / cpt, cc = kt - tap * cpt;
             const int dy = tap / p.ckw - cpad, dx = tap % p.ckw - cpad;
-            const int delta = (dy * p.cW + dx) * p.cCin + cc * 64;
+            const int delta = (dy * p.cW + dx) * p.cCin + cc * BK;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xFFFF) + dx;
@@ -194,10 +221,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) glds16(a_src[i] + kt * 64, s + (i * NW + wave) * 1024);
+            for (int i = 0; i < NA; ++i) glds16(a_src[i] + kt * BK, s + (i * NW + wave) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16(b_src[i] + kt * 64, s + A_BYTES + (i * NW + wave) * 1024);
+        for (int i = 0; i < NB; ++i) glds16(b_src[i] + kt * BK, s + A_BYTES + (i * NW + wave) * 1024);
     };
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -205,19 +232,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
         __syncthreads();
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* s = smem + (kt & 1) * STAGE;
+        // all 4 k-substeps' fragments are requested up front (64 VGPRs) so the LDS latency of
+        // substep s+1.. hides under the MFMAs of substep s (hipcc otherwise emits
+        // read4 -> lgkmcnt(0) -> mfma4 -> read4 ..., measured: LDS phase + MFMA phase serialised)
+        v8 af[KS][TM], bf[KS][TN];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int coff = ((2 * ks + h) ^ swz) << 4;
-            v8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const v8*)(s + a_row_off + i * 32 * 128 + coff);
+            for (int i = 0; i < TM; ++i) af[ks][i] = *(const v8*)(s + a_row_off + i * 32 * ROWB + coff);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const v8*)(s + b_row_off + j * 32 * 128 + coff);
+            for (int j = 0; j < TN; ++j) bf[ks][j] = *(const v8*)(s + b_row_off + j * 32 * ROWB + coff);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
-        }
+                for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
     }
 
     // ---- epilogue: accumulators -> wave-private LDS -> full-row segments ----
@@ -226,8 +258,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
     constexpr int LPR = TN * 8, RPI = 64 / LPR;   // lanes per row, rows per read instr
     float* ep = (float*)(smem + wave * (32 * ROWF * 4));
     const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+    const int gn = n0 + wn * (BN / WN) + rcol;
+    const bool col_ok = gn < p.N;
+    const int gnc = col_ok ? gn : 0;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
+    if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
+    if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        // issue this pass's global loads first: they fly while the accumulators go through LDS
+        constexpr int NIT = 32 / RPI;
+        f32x4 ext[NIT];
+        float rs[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int gmc = min(m0 + wm * (BM / WM) + i * 32 + it * RPI + rrow, p.M - 1);
+            ext[it] = epilogue_ext<T, EPI>(p, gmc, gnc);
+            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[gmc] : 1.f;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -236,17 +284,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 v[NIT];
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
+        for (int it = 0; it < NIT; ++it) v[it] = *(const f32x4*)(ep + (it * RPI + rrow) * ROWF + rcol);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + rrow;
-            const f32x4 v = *(const f32x4*)(ep + row * ROWF + rcol);
             const int gm = m0 + wm * (BM / WM) + i * 32 + row;
-            const int gn = n0 + wn * (BN / WN) + rcol;
             if constexpr (EPI == EPI_ARGMAX) {
                 // fused arg-max over the vocabulary (modeling_discrete_vae.py:246-248): per row, the best
                 // (value, index) of this wave's ROWF columns -> partial[gm][chunk]; logits never reach HBM
-                f32x4 vv = v;
-                if (p.e.bias && gn < p.N) vv += *(const f32x4*)(p.e.bias + gn);
+                f32x4 vv = v[it] + bias4;
                 float best = -INFINITY;
                 int bi = 0x7fffffff;
 #pragma unroll
@@ -271,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT p) {
                     ((int*)pv)[1] = bi;
                 }
             } else {
-                if (gm < p.M && gn < p.N) epilogue4<T, EPI>(p, gm, gn, v);
+                if (gm < p.M && col_ok) epilogue4<T, EPI>(p, gm, gn, v[it], bias4, gamma4, ext[it], rs[it]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -401,14 +449,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV = false, int BK = 64>
 int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
     dim3 grid(tiles), block(WM * WN * 64);
 #define VLMO_LAUNCH_EPI(E)                                                                     \
     case E: {                                                                                  \
-        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV>;                                         \
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV, BK>;                                         \
         if (LDS > 65536) {                                                                     \
             static bool attr_set = false;                                                      \
             if (!attr_set) {                                                                   \
@@ -461,12 +509,22 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     VLMO_CHECK_ARG(epi != EPI_RESID || e->resid, "vlmo_gemm_nt: residual epilogue needs resid");
     VLMO_CHECK_ARG(epi != EPI_DGELU || (e->aux && e->ld2 >= N), "vlmo_gemm_nt: dgelu epilogue needs aux");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_nt: dtype must be bf16 or f16");
-    GemmNT p{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr};
+    GemmNT p{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, 8};
+    if (const char* sv = getenv("VLMO_GROUP_M")) p.group_m = atoi(sv);
+    if (tile < 0) {
+        // measured on MI355X (tools/gemm_bench.py): deep reductions are load-latency bound and want the
+        // 2x higher arithmetic intensity of the 256x256 tile (one workgroup/CU); shallow ones (K = d) are
+        // epilogue bound and want two 128x128 workgroups per CU so one's stores overlap the other's MFMAs
+        tile = (K >= 1536 && M >= 2048 && N >= 512) ? 3 : 0;
+    }
     if (dtype == VLMO_F16) {
         if (tile == 1) return launch_nt<f16, 256, 128, 4, 2>(epi, p, stream);
+        if (tile == 3) return launch_nt<f16, 256, 256, 2, 4>(epi, p, stream);
         return launch_nt<f16, 128, 128, 2, 2>(epi, p, stream);
     }
     if (tile == 1) return launch_nt<bf16, 256, 128, 4, 2>(epi, p, stream);
+    if (tile == 2) return launch_nt<bf16, 128, 128, 2, 2, false, 32>(epi, p, stream);
+    if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
 }
 
@@ -479,8 +537,14 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn: dtype must be bf16 or f16");
     const int nk = (M + 63) / 64;
     const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
-    if (splits <= 0) {  // aim for ~3 workgroups per CU
-        splits = (768 + tiles - 1) / tiles;
+    if (splits <= 0) {
+        // every split adds N1*N2*4 bytes of fp32 atomics (~1.3 TB/s chip-wide): use the fewest splits that
+        // still give about two workgroups per CU
+        // still fill whole dispatch rounds (512 workgroup slots = 2 per CU): measured on MI355X, a last
+        // round that is mostly empty costs more than the extra atomics of a fuller one
+        splits = 512 / tiles;
+        if (splits < 4) splits = 1024 / tiles;
+        if (splits < 1) splits = 1;
     }
     if (splits > nk) splits = nk;
     const int per = (nk + splits - 1) / splits;
@@ -507,7 +571,7 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     VLMO_CHECK_ARG(e->out && e->ldo >= Cout, "vlmo_conv2d_nhwc: bad output");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_conv2d_nhwc: dtype must be bf16 or f16");
     const int K = kw * kw * Cin;
-    GemmNT p{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page};
+    GemmNT p{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8};
     if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);
 }

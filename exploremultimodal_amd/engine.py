@@ -16,7 +16,7 @@ import torch
 from . import hip
 
 LN_EPS = 1e-12          # vlmo_module.py:21-23
-DEFAULT_TILE = 0         # GEMM tile: 0 = 128x128 (2 workgroups/CU), 1 = 256x128
+DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
 
 class ShadowCache:

@@ -130,7 +130,7 @@ def drop_params(p, training):
 
 def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=None,
             row_scale=None, aux=None, ldo=None, ld2=None, relu=False, drop=(0, 1.0), seed=0,
-            beta=0.0, tile=0, lda=None, ldb=None):
+            beta=0.0, tile=-1, lda=None, ldb=None):
     e = Epilogue(_p(out), _p(out2), _p(bias), _p(gamma), _p(resid), _p(row_scale), _p(aux),
                  ldo if ldo is not None else out.stride(0),
                  ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else

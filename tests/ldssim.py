@@ -130,3 +130,15 @@ def att_tr_addr(row_base, col_base, lane):
     row = row_base + 4 * h + q
     col = col_base + 16 * (g & 1) + 4 * pp
     return att_off(row, col >> 3) + (col & 7) * 2
+
+
+def nt32_stage_src(instr, lane):
+    """gemm_nt_kernel<BK=32> staging: 64-byte rows, 16 rows per wave-instruction."""
+    r = instr * 16 + (lane >> 2)
+    c = (lane & 3) ^ ((r >> 2) & 3)
+    return r, c
+
+
+def nt32_frag_addr(row, ks, lane):
+    h = lane >> 5
+    return row * 64 + (((2 * ks + h) ^ ((row >> 2) & 3)) << 4)

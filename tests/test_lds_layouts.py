@@ -90,3 +90,23 @@ def test_attention_dual_use_image():
                         np.testing.assert_array_equal(got[l], ids[r0:r0 + 4, dcol])
                     worst = max(worst, S.tr_conflicts(addrs))
     assert worst == 1
+
+
+def test_gemm_nt_bk32_image():
+    ids = _ids(128, 32)
+    lds = S.Lds(128 * 64)
+    for instr in range(8):
+        src = []
+        for lane in range(64):
+            r, c = S.nt32_stage_src(instr, lane)
+            src.append(ids[r, c * 8:c * 8 + 8])
+        lds.dma16(instr * 1024, src)
+    assert (lds.ids >= 0).all()
+    for row_base in (0, 32, 64, 96):
+        for ks in range(2):
+            addrs = [S.nt32_frag_addr(row_base + (l & 31), ks, l) for l in range(64)]
+            got = lds.read_b128(addrs)
+            for l in range(64):
+                k0 = 16 * ks + 8 * (l >> 5)
+                np.testing.assert_array_equal(got[l], ids[row_base + (l & 31), k0:k0 + 8])
+            assert S.b128_conflicts(addrs) == 1
