@@ -16,6 +16,7 @@ import torch
 from . import hip
 
 LN_EPS = 1e-12          # vlmo_module.py:21-23
+OVERLAP_WGRAD = True     # weight-gradient GEMMs + bias column sums on a side stream beside the dgrad chain
 DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
 
@@ -112,6 +113,41 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _SIDE[dev] = s
+    return s
+
+
+class _Fork:
+    """Run weight-gradient work on a side stream: fork() after the producers were enqueued on the main
+    stream, join() before the buffers it reads may be reused.  Off = everything on the main stream."""
+
+    def __init__(self, dev, enabled):
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _side_stream(dev) if enabled else None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            self._ctx.__exit__(*a)
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+
 class BlockFn(torch.autograd.Function):
     """One VLMo Block (vlmo.py:187-197) = norm1 -> qkv -> attention -> proj(+gamma_1,
     residual) -> norm2 -> expert FFN(+gamma_2, residual).  params order:
@@ -195,6 +231,7 @@ class BlockFn(torch.autograd.Function):
         dg1, dg2, dn1w, dn1b, dn2w, dn2b = z(d), z(d), z(d), z(d), z(d), z(d)
         dqkv_w, dproj_w, dproj_b = z(3 * d, d), z(d, d), z(d)
         dexp = []
+        fork = _Fork(dev, OVERLAP_WGRAD)
         # ---- FFN half
         dz2 = _empty((M, d), bf, dev)
         du = _empty((M, hid), bf, dev)
@@ -206,30 +243,34 @@ class BlockFn(torch.autograd.Function):
                           n, d, drop=meta.drop, seed=seed + 21 + 2 * ei)
             hip.gemm_nt(hip.EPI_DGELU, dz2[sl], sh.get(w2)[1], n, hid, d, du[sl], aux=u[sl], drop=meta.drop,
                         seed=seed + 20 + 2 * ei, tile=meta.tile)
-            hip.gemm_tn(dz2[sl], hh[sl], dw2, n, d, hid)
-            hip.colsum(du[sl], db1, n, hid)
+            with fork:      # off the critical path: dW2, db1, dW1
+                hip.gemm_tn(dz2[sl], hh[sl], dw2, n, d, hid)
+                hip.colsum(du[sl], db1, n, hid)
+                hip.gemm_tn(du[sl], y2[sl], dw1, n, hid, d)
             hip.gemm_nt(hip.EPI_BIAS, du[sl], sh.get(w1)[1], n, d, hid, dy2[sl], tile=meta.tile)
-            hip.gemm_tn(du[sl], y2[sl], dw1, n, hid, d)
             dexp += [dw1, db1, dw2, db2]
         dx1 = _empty((M, d), f32, dev)
         hip.ln_bwd(dy2, None, x1, n2w, mean2, rstd2, dx2, dx1, dn2w, dn2b, M, d)
         # ---- attention half
-        dz1 = dz2          # reuse
+        dz1 = _empty((M, d), bf, dev)      # not aliased with dz2: the side stream may still read dz2
         hip.resid_bwd(dx1, zd1, g1, meta.rs1, dz1, dg1, dproj_b, M, d, drop=meta.drop, seed=seed + 1)
-        dctx = dy2         # reuse
+        dctx = dy2         # reuse: dy2 was consumed by ln_bwd above on this stream, never read on the side
         hip.gemm_nt(hip.EPI_BIAS, dz1, sh.get(proj_w)[1], M, d, d, dctx, tile=meta.tile)
-        hip.gemm_tn(dz1, ctxb, dproj_w, M, d, d)
+        with fork:
+            hip.gemm_tn(dz1, ctxb, dproj_w, M, d, d)
         dqkv = _empty((M, 3 * d), bf, dev)
         for li, ((seg, nseq, maxlen), lse) in enumerate(zip(pl.attn_launches(meta.fused), lses)):
             hip.attn_bwd(qkv, ctxb, dctx, lse, seg, nseq, pl.keymask, dqkv, H, d, maxlen, (d // H) ** -0.5,
                          drop=meta.attn_drop, seed=seed + 11 + li)
         dqkv_b = z(3 * d)
-        hip.colsum(dqkv, dqkv_b, M, 3 * d)
+        with fork:
+            hip.colsum(dqkv, dqkv_b, M, 3 * d)
+            hip.gemm_tn(dqkv, y1, dqkv_w, M, 3 * d, d)
         dy1 = _empty((M, d), bf, dev)
         hip.gemm_nt(hip.EPI_BIAS, dqkv, sh.get(qkv_w)[1], M, d, 3 * d, dy1, tile=meta.tile)
-        hip.gemm_tn(dqkv, y1, dqkv_w, M, 3 * d, d)
         dx0 = _empty((M, d), f32, dev)
         hip.ln_bwd(dy1, None, x, n1w, mean1, rstd1, dx1, dx0, dn1w, dn1b, M, d)
+        fork.join()        # gradients are complete (and every buffer the side stream read is free) from here
         grads = [dg1, dg2, dn1w, dn1b, dqkv_w, dqkv_b[:d], dqkv_b[2 * d:], dproj_w, dproj_b, dn2w, dn2b] + dexp
         return (dx0, None, *grads)
 

@@ -109,12 +109,14 @@ _WS = {}
 
 
 def workspace(device, ncols):
-    """Persistent per-device scratch for the column-reducing kernels (stream-ordered reuse)."""
+    """Persistent scratch for the column-reducing kernels, one per (device, stream): reuse is ordered by
+    the stream, and kernels on different streams never share a buffer."""
     need = lib().vlmo_reduce_ws_bytes(ncols)
-    ws = _WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(max(need, 1 << 23) // 4, dtype=torch.float32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 
