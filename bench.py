@@ -200,6 +200,15 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
                     'launches_per_step': n // args.steps, 'avg_launch_us': round(tsec / n * 1e6, 2),
                     'flops_per_launch': round(flops / n)}
+        if roof is not None:        # HBM bytes per launch from the committed PMC passes of this same command
+            try:
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['kernels']
+                for k, v in tr.items():
+                    if roof['kernel'].split('<')[0] in k and (roof['kernel'].startswith('gemm_tn') or 'Li' in k):
+                        roof['traffic'] = round(v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
+                        break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             'metric': 'image-text pairs/sec fwd+bwd, VLMo-Base, 1/2/4/8 MI355X; % bf16 MFMA roofline',
             'value': round(pairs, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
