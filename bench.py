@@ -163,34 +163,28 @@ def main():
             log('first step done')
     barrier()
     log('warm-up done')
-    hip.PROFILE = {}                      # HIP-event pairs around the GEMM launches of the timed region
+    hip.profile_start()                   # HIP-event pairs around every GEMM launch of the timed region (in-library)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_issue = time.perf_counter() - t0    # host time to ENQUEUE the steps (launch-bound if close to dt)
     barrier()
     dt = time.perf_counter() - t0
-    prof, hip.PROFILE = hip.PROFILE, None
+    prof = hip.profile_stop()
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item(), 'non-finite loss'
 
-    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
+    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue {t_issue / args.steps * 1e3:.2f} ms/step)')
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = B * world * args.steps / dt
         fl = 3 * fwd_flops_per_pair(mc.embed_dim, mc.depth, mc.fusion_layer, mc.max_text_len, P,
                                     mc.in_chans * mc.patch_size ** 2)
         # dominant kernel: per-symbol totals from the event pairs recorded in the timed region
-        per = {}
-        for key, evs in prof.items():
-            sym, flops = key[0], key[1]
-            tot = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
-            e = per.setdefault(sym, [0.0, 0.0, 0])
-            e[0] += tot
-            e[1] += flops * len(evs)
-            e[2] += len(evs)
+        per = {sym: [sec, flops, n] for sym, (sec, flops, n) in prof.items()}
         dom = max(per.items(), key=lambda kv: kv[1][0]) if per else None
         roof = None
         if dom:

@@ -1,0 +1,170 @@
+// One VLMo Block forward / backward per C-ABI call (vlmo.py:187-197): native orchestration
+// of the kernels in gemm.hip / attention.hip / layernorm.hip / elementwise.hip, so the Python
+// host issues one FFI call per block and stays far ahead of the GPU.
+#include "common.h"
+#include "vlmo_hip.h"
+
+namespace {
+
+struct Events {
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+Events& events() {
+    static thread_local Events e;
+    if (!e.fork) {
+        (void)hipEventCreateWithFlags(&e.fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&e.join, hipEventDisableTiming);
+    }
+    return e;
+}
+
+inline const char* bp(const void* p, size_t row, size_t ld, size_t esz) { return (const char*)p + row * ld * esz; }
+inline char* bp(void* p, size_t row, size_t ld, size_t esz) { return (char*)p + row * ld * esz; }
+
+#define TRY(x)              \
+    do {                    \
+        int rc__ = (x);     \
+        if (rc__) return rc__; \
+    } while (0)
+
+VlmoEpilogue epi() {
+    VlmoEpilogue e{};
+    e.inv_keep = 1.f;
+    return e;
+}
+
+}  // namespace
+
+extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
+    VLMO_CHECK_ARG(b && b->x && b->x1 && b->x2, "vlmo_block_fwd: null descriptor/buffers");
+    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 2 && b->n_attn >= 1 && b->n_attn <= 2, "vlmo_block_fwd: bad counts");
+    const int M = b->M, d = b->d, hid = b->hidden;
+    TRY(vlmo_ln_fwd(b->x, b->n1w, b->n1b, b->y1, 0, b->mean1, b->rstd1, nullptr, M, d, b->eps, st));
+    {
+        VlmoEpilogue e = epi();
+        e.out = b->qkv;
+        e.ldo = 3 * d;
+        e.bias = b->qkv_bias;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->y1, d, b->qkv_w, d, M, 3 * d, d, &e, st));
+    }
+    const float scale = 1.0f / sqrtf((float)(d / b->heads));
+    for (int a = 0; a < b->n_attn; ++a)
+        TRY(vlmo_attn_fwd(b->qkv, b->seg[a], b->nseq[a], b->keymask, b->ctx, b->lse[a], b->lse_stride[a], b->heads, d,
+                          b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep, b->seed + 11 + a, st));
+    {
+        VlmoEpilogue e = epi();
+        e.out = b->x1;
+        e.ldo = d;
+        e.out2 = b->need_bwd ? b->zd1 : nullptr;
+        e.ld2 = d;
+        e.bias = b->proj_b;
+        e.gamma = b->g1;
+        e.resid = b->x;
+        e.row_scale = b->rs1;
+        e.drop_thresh = b->drop_thresh;
+        e.inv_keep = b->inv_keep;
+        e.seed = b->seed + 1;
+        TRY(vlmo_gemm_nt(VLMO_EPI_RESID, VLMO_BF16, b->tile, b->ctx, d, b->proj_w, d, M, d, d, &e, st));
+    }
+    TRY(vlmo_ln_fwd(b->x1, b->n2w, b->n2b, b->y2, 0, b->mean2, b->rstd2, nullptr, M, d, b->eps, st));
+    for (int x = 0; x < b->n_experts; ++x) {
+        const size_t r0 = b->exp_row0[x];
+        const int n = b->exp_rows[x];
+        VlmoEpilogue e = epi();
+        e.out = bp(b->u, r0, hid, 2);
+        e.out2 = bp(b->h, r0, hid, 2);
+        e.ldo = e.ld2 = hid;
+        e.bias = b->b1[x];
+        e.drop_thresh = b->drop_thresh;
+        e.inv_keep = b->inv_keep;
+        e.seed = b->seed + 20 + 2 * x;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS_GELU, VLMO_BF16, b->tile, bp(b->y2, r0, d, 2), d, b->w1[x], d, n, hid, d, &e, st));
+        VlmoEpilogue f = epi();
+        f.out = bp(b->x2, r0, d, 4);
+        f.ldo = d;
+        f.out2 = b->need_bwd ? bp(b->zd2, r0, d, 2) : nullptr;
+        f.ld2 = d;
+        f.bias = b->b2[x];
+        f.gamma = b->g2;
+        f.resid = (const float*)bp((const void*)b->x1, r0, d, 4);
+        f.row_scale = b->rs2 ? b->rs2 + r0 : nullptr;
+        f.drop_thresh = b->drop_thresh;
+        f.inv_keep = b->inv_keep;
+        f.seed = b->seed + 21 + 2 * x;
+        TRY(vlmo_gemm_nt(VLMO_EPI_RESID, VLMO_BF16, b->tile, bp(b->h, r0, hid, 2), hid, b->w2[x], hid, n, d, hid, &f, st));
+    }
+    return 0;
+}
+
+extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
+    VLMO_CHECK_ARG(b && b->dx2 && b->dx1 && b->dx0, "vlmo_block_bwd: null descriptor/buffers");
+    const int M = b->M, d = b->d, hid = b->hidden;
+    hipStream_t side = b->side_stream ? b->side_stream : st;
+    float* ws_side = b->side_stream ? b->ws_side : b->ws_main;
+    Events& ev = events();
+    auto fork = [&]() {     // side stream may read everything enqueued on the main stream so far
+        if (side != st) {
+            (void)hipEventRecord(ev.fork, st);
+            (void)hipStreamWaitEvent(side, ev.fork, 0);
+        }
+    };
+    // ---- FFN half
+    for (int x = 0; x < b->n_experts; ++x) {
+        const size_t r0 = b->exp_row0[x];
+        const int n = b->exp_rows[x];
+        TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2, b->rs2 ? b->rs2 + r0 : nullptr,
+                           bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d, b->drop_thresh, b->inv_keep,
+                           b->seed + 21 + 2 * x, b->ws_main, b->ws_bytes, st));
+        VlmoEpilogue e = epi();
+        e.out = bp(b->du, r0, hid, 2);
+        e.ldo = hid;
+        e.aux = bp(b->u, r0, hid, 2);
+        e.ld2 = hid;
+        e.drop_thresh = b->drop_thresh;
+        e.inv_keep = b->inv_keep;
+        e.seed = b->seed + 20 + 2 * x;
+        TRY(vlmo_gemm_nt(VLMO_EPI_DGELU, VLMO_BF16, b->tile, bp(b->dz2, r0, d, 2), d, b->w2T[x], d, n, hid, d, &e, st));
+        fork();
+        TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid, 1.f, 0, side));
+        TRY(vlmo_colsum(VLMO_BF16, bp(b->du, r0, hid, 2), hid, b->db1[x], n, hid, ws_side, b->ws_bytes, side));
+        TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d, 1.f, 0, side));
+        VlmoEpilogue f = epi();
+        f.out = bp(b->dy2, r0, d, 2);
+        f.ldo = d;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, bp(b->du, r0, hid, 2), hid, b->w1T[x], hid, n, d, hid, &f, st));
+    }
+    TRY(vlmo_ln_bwd(b->dy2, 0, nullptr, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, M, d,
+                    b->ws_main, b->ws_bytes, st));
+    // ---- attention half
+    TRY(vlmo_resid_bwd(b->dx1, b->zd1, b->g1, b->rs1, b->dz1, b->dg1, b->dproj_b, M, d, b->drop_thresh, b->inv_keep,
+                       b->seed + 1, b->ws_main, b->ws_bytes, st));
+    {
+        VlmoEpilogue e = epi();
+        e.out = b->dctx;
+        e.ldo = d;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dz1, d, b->proj_wT, d, M, d, d, &e, st));
+    }
+    fork();
+    TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, side));
+    const float scale = 1.0f / sqrtf((float)(d / b->heads));
+    for (int a = 0; a < b->n_attn; ++a)
+        TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
+                          b->dqkv, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
+                          b->seed + 11 + a, st));
+    fork();
+    TRY(vlmo_colsum(VLMO_BF16, b->dqkv, 3 * d, b->dqkv_b, M, 3 * d, ws_side, b->ws_bytes, side));
+    TRY(vlmo_gemm_tn(VLMO_BF16, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d, 1.f, 0, side));
+    {
+        VlmoEpilogue e = epi();
+        e.out = b->dy1;
+        e.ldo = d;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dqkv, 3 * d, b->qkv_wT, 3 * d, M, d, 3 * d, &e, st));
+    }
+    TRY(vlmo_ln_bwd(b->dy1, 0, nullptr, b->x, b->n1w, b->mean1, b->rstd1, b->dx1, b->dx0, b->dn1w, b->dn1b, M, d,
+                    b->ws_main, b->ws_bytes, st));
+    if (side != st) {       // join: gradients complete, every buffer the side stream read is reusable
+        (void)hipEventRecord(ev.join, side);
+        (void)hipStreamWaitEvent(st, ev.join, 0);
+    }
+    return 0;
+}

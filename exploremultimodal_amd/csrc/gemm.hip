@@ -17,6 +17,8 @@
 #include "common.h"
 #include "vlmo_hip.h"
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -496,6 +498,76 @@ int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
 
 }  // namespace
 
+// ---- optional in-library timing of GEMM launches (bench.py's roofline): HIP event pairs recorded on the
+// launch stream around every vlmo_gemm_nt / vlmo_gemm_tn / vlmo_conv2d_nhwc while profiling is on.
+namespace {
+struct ProfRec {
+    hipEvent_t a, b;
+    int tag;
+    double flops;
+};
+struct Prof {
+    std::vector<ProfRec> recs;
+    size_t used = 0;
+    bool on = false;
+    std::mutex mu;
+} g_prof;
+
+struct ProfScope {
+    ProfRec* r = nullptr;
+    hipStream_t st;
+    ProfScope(int tag, double flops, hipStream_t s) : st(s) {
+        if (!g_prof.on) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.used < g_prof.recs.size()) {
+            r = &g_prof.recs[g_prof.used++];
+            r->tag = tag;
+            r->flops = flops;
+            (void)hipEventRecord(r->a, st);
+        }
+    }
+    ~ProfScope() {
+        if (r) (void)hipEventRecord(r->b, st);
+    }
+};
+}  // namespace
+
+extern "C" int vlmo_profile_start(int max_records) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    while ((int)g_prof.recs.size() < max_records) {
+        ProfRec r{};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            vlmo_set_error("vlmo_profile_start: hipEventCreate failed");
+            return -1;
+        }
+        g_prof.recs.push_back(r);
+    }
+    g_prof.used = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+// Stops recording and sums per tag (tag = epilogue id for gemm_nt, 32 + epilogue for conv, 64 for gemm_tn;
+// +8 when the 256x256 tile ran).  Call after the stream(s) have been synchronised.
+extern "C" int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = false;
+    for (int i = 0; i < ntags; ++i) {
+        ms[i] = 0;
+        flops[i] = 0;
+        launches[i] = 0;
+    }
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        const ProfRec& r = g_prof.recs[i];
+        float t = 0.f;
+        if (r.tag < 0 || r.tag >= ntags || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+        ms[r.tag] += t;
+        flops[r.tag] += r.flops;
+        launches[r.tag] += 1;
+    }
+    return (int)g_prof.used;
+}
+
 extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
                             int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream) {
     VLMO_CHECK_ARG(A && B && e, "vlmo_gemm_nt: null operand");
@@ -517,6 +589,7 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
         // epilogue bound and want two 128x128 workgroups per CU so one's stores overlap the other's MFMAs
         tile = (K >= 1536 && M >= 2048 && N >= 512) ? 3 : 0;
     }
+    ProfScope prof(epi + (tile == 3 ? 8 : 0), 2.0 * M * N * K, stream);
     if (dtype == VLMO_F16) {
         if (tile == 1) return launch_nt<f16, 256, 128, 4, 2>(epi, p, stream);
         if (tile == 3) return launch_nt<f16, 256, 256, 2, 4>(epi, p, stream);
@@ -551,6 +624,7 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     splits = (nk + per - 1) / per;
     GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, per, alpha};
     dim3 grid(tiles, splits), block(256);
+    ProfScope prof(64, 2.0 * M * N1 * N2, stream);
     if (dtype == VLMO_F16)
         hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, 65536, stream, p);
     else
@@ -572,6 +646,7 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_conv2d_nhwc: dtype must be bf16 or f16");
     const int K = kw * kw * Cin;
     GemmNT p{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8};
+    ProfScope prof(32 + epi, 2.0 * B * H * W * Cout * K, stream);
     if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);
 }

@@ -44,14 +44,22 @@ class ShadowCache:
         self._c.clear()
 
 
-class Plan:
-    """Row layout + attention launches of one backbone pass."""
+class _PlanStatic:
+    """Shape-only part of a plan (segment descriptors, row maps): built once per (B, T, P, device).
+    Building it copies a few small host tensors to the device, which would stall the host every pass."""
+    _cache = {}
 
-    def __init__(self, B, T, P, device, txt_mask=None, img_mask=None):
-        self.B, self.T, self.P = B, T, P
-        self.nt, self.ni = B * T, B * P
-        self.M = self.nt + self.ni
-        self.device = device
+    @classmethod
+    def get(cls, B, T, P, device):
+        key = (B, T, P, str(device))
+        st = cls._cache.get(key)
+        if st is None:
+            st = cls(B, T, P, device)
+            cls._cache[key] = st
+        return st
+
+    def __init__(self, B, T, P, device):
+        nt = B * T
         ar = torch.arange(B, dtype=torch.int32)
         z = torch.zeros(B, dtype=torch.int32)
 
@@ -60,8 +68,29 @@ class Plan:
 
         tl, pl = torch.full((B,), T, dtype=torch.int32), torch.full((B,), P, dtype=torch.int32)
         self.seg_txt = seg(ar * T, tl, z, z) if T else None
-        self.seg_img = seg(self.nt + ar * P, pl, z, z) if P else None
-        self.seg_vl = seg(ar * T, tl, self.nt + ar * P, pl) if (T and P) else None
+        self.seg_img = seg(nt + ar * P, pl, z, z) if P else None
+        self.seg_vl = seg(ar * T, tl, nt + ar * P, pl) if (T and P) else None
+        # packed row -> row of the [B, T+P, d] output (text first, vlmo.py:406)
+        N = T + P
+        rm_t = (torch.arange(B).view(B, 1) * N + torch.arange(T).view(1, T)).reshape(-1)
+        rm_i = (torch.arange(B).view(B, 1) * N + T + torch.arange(P).view(1, P)).reshape(-1)
+        self.rowmap = torch.cat([rm_t, rm_i]).to(torch.int32).to(device)
+        # sample index of every packed row (drop-path scale expansion)
+        self.row_sample_txt = torch.arange(B).repeat_interleave(T).to(device) if T else None
+        self.row_sample_img = torch.arange(B).repeat_interleave(P).to(device) if P else None
+
+
+class Plan:
+    """Row layout + attention launches of one backbone pass."""
+
+    def __init__(self, B, T, P, device, txt_mask=None, img_mask=None):
+        self.B, self.T, self.P = B, T, P
+        self.nt, self.ni = B * T, B * P
+        self.M = self.nt + self.ni
+        self.device = device
+        st = _PlanStatic.get(B, T, P, device)
+        self.seg_txt, self.seg_img, self.seg_vl = st.seg_txt, st.seg_img, st.seg_vl
+        self.rowmap, self.row_sample_txt, self.row_sample_img = st.rowmap, st.row_sample_txt, st.row_sample_img
         # key-padding mask over packed rows (vlmo.py:89-91); None = all valid
         parts = []
         if T:
@@ -71,14 +100,6 @@ class Plan:
             parts.append(img_mask.reshape(-1).to(torch.int32) if img_mask is not None
                          else torch.ones(self.ni, dtype=torch.int32, device=device))
         self.keymask = torch.cat(parts).contiguous() if (txt_mask is not None or img_mask is not None) else None
-        # packed row -> row of the [B, T+P, d] output (text first, vlmo.py:406)
-        N = T + P
-        rm_t = (torch.arange(B).view(B, 1) * N + torch.arange(T).view(1, T)).reshape(-1)
-        rm_i = (torch.arange(B).view(B, 1) * N + T + torch.arange(P).view(1, P)).reshape(-1)
-        self.rowmap = torch.cat([rm_t, rm_i]).to(torch.int32).to(device)
-        # sample index of every packed row (drop-path scale expansion)
-        self.row_sample_txt = torch.arange(B).repeat_interleave(T).to(device) if T else None
-        self.row_sample_img = torch.arange(B).repeat_interleave(P).to(device) if P else None
 
     def attn_launches(self, fused):
         if fused and self.seg_vl is not None:
@@ -149,73 +170,86 @@ class _Fork:
 
 
 class BlockFn(torch.autograd.Function):
-    """One VLMo Block (vlmo.py:187-197) = norm1 -> qkv -> attention -> proj(+gamma_1,
-    residual) -> norm2 -> expert FFN(+gamma_2, residual).  params order:
-    gamma_1, gamma_2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b,
+    """One VLMo Block (vlmo.py:187-197) = norm1 -> qkv -> attention -> proj(+gamma_1, residual) -> norm2 ->
+    expert FFN(+gamma_2, residual), forward and backward each ONE native call (vlmo_block_fwd / vlmo_block_bwd).
+    params order: gamma_1, gamma_2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b,
     then (fc1_w, fc1_b, fc2_w, fc2_b) per expert range."""
 
     @staticmethod
     def forward(ctx, x, meta, *params):
         (g1, g2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b) = params[:11]
-        experts = [params[11 + 4 * i: 15 + 4 * i] for i in range(len(meta.expert_ranges))]
+        nexp = len(meta.expert_ranges)
+        experts = [params[11 + 4 * i: 15 + 4 * i] for i in range(nexp)]
         pl, d, H, hid = meta.plan, meta.d, meta.heads, meta.hidden
         M, dev = x.shape[0], x.device
-        bf, f32 = torch.bfloat16, torch.float32
         sh = meta.shadows
         need_bwd = any(ctx.needs_input_grad)   # grad mode is off inside forward; this reflects the caller's
-        seed = meta.seed
-
-        y1, mean1, rstd1 = _empty((M, d), bf, dev), _empty((M,), f32, dev), _empty((M,), f32, dev)
-        hip.ln_fwd(x, n1w, n1b, y1, mean1, rstd1, None, M, d, meta.eps)
-        qkv_bias = torch.cat([q_bias.detach(), torch.zeros_like(q_bias), v_bias.detach()])   # vlmo.py:72-75
-        qkv = _empty((M, 3 * d), bf, dev)
-        hip.gemm_nt(hip.EPI_BIAS, y1, sh.get(qkv_w)[0], M, 3 * d, d, qkv, bias=qkv_bias, tile=meta.tile)
-        ctxb = _empty((M, d), bf, dev)
+        x = x.contiguous()
         launches = pl.attn_launches(meta.fused)
-        lses = []
-        for li, (seg, nseq, maxlen) in enumerate(launches):
-            npad = ((maxlen + 31) // 32) * 32
-            lse = _empty((nseq * H, npad), f32, dev)
-            hip.attn_fwd(qkv, seg, nseq, pl.keymask, ctxb, lse, H, d, maxlen, (d // H) ** -0.5,
-                         drop=meta.attn_drop, seed=seed + 11 + li)
-            lses.append(lse)
-        x1 = _empty((M, d), f32, dev)
-        zd1 = _empty((M, d), bf, dev) if need_bwd else None
-        hip.gemm_nt(hip.EPI_RESID, ctxb, sh.get(proj_w)[0], M, d, d, x1, out2=zd1, bias=proj_b, gamma=g1,
-                    resid=x, row_scale=meta.rs1, drop=meta.drop, seed=seed + 1, tile=meta.tile)
-        y2, mean2, rstd2 = _empty((M, d), bf, dev), _empty((M,), f32, dev), _empty((M,), f32, dev)
-        hip.ln_fwd(x1, n2w, n2b, y2, mean2, rstd2, None, M, d, meta.eps)
-        u, hh = _empty((M, hid), bf, dev), _empty((M, hid), bf, dev)
-        x2 = _empty((M, d), f32, dev)
-        zd2 = _empty((M, d), bf, dev) if need_bwd else None
-        for ei, ((r0, n), (w1, b1, w2, b2)) in enumerate(zip(meta.expert_ranges, experts)):
-            hip.gemm_nt(hip.EPI_BIAS_GELU, y2[r0:r0 + n], sh.get(w1)[0], n, hid, d, u[r0:r0 + n],
-                        out2=hh[r0:r0 + n], bias=b1, drop=meta.drop, seed=seed + 20 + 2 * ei, tile=meta.tile)
-            hip.gemm_nt(hip.EPI_RESID, hh[r0:r0 + n], sh.get(w2)[0], n, d, hid, x2[r0:r0 + n],
-                        out2=zd2[r0:r0 + n] if zd2 is not None else None, bias=b2, gamma=g2,
-                        resid=x1[r0:r0 + n], row_scale=meta.rs2[r0:r0 + n] if meta.rs2 is not None else None,
-                        drop=meta.drop, seed=seed + 21 + 2 * ei, tile=meta.tile)
+        lse_sizes = [nseq * H * (((ml + 31) // 32) * 32) for _, nseq, ml in launches]
+        # one bf16 slab: y1 | qkv(3) | ctx | zd1 | y2 | u(4) | h(4) | zd2  (units of M*d) ; one fp32 slab
+        sb = torch.empty(16 * M * d, dtype=torch.bfloat16, device=dev)
+        sf = torch.empty(M * d + 4 * M + sum(lse_sizes), dtype=torch.float32, device=dev)
+        x2 = torch.empty((M, d), dtype=torch.float32, device=dev)
+        qkv_bias = torch.cat([q_bias.detach(), torch.zeros_like(q_bias), v_bias.detach()])   # vlmo.py:72-75
+        D = hip.BlockDesc()
+        D.M, D.d, D.hidden, D.heads = M, d, hid, H
+        D.n_experts = nexp
+        for i, (r0, n) in enumerate(meta.expert_ranges):
+            D.exp_row0[i], D.exp_rows[i] = r0, n
+        D.n_attn = len(launches)
+        pb, pf = sb.data_ptr(), sf.data_ptr()
+        md2 = M * d * 2
+        D.y1, D.qkv, D.ctx, D.zd1, D.y2 = pb, pb + md2, pb + 4 * md2, pb + 5 * md2, pb + 6 * md2
+        D.u, D.h, D.zd2 = pb + 7 * md2, pb + 11 * md2, pb + 15 * md2
+        D.x1 = pf
+        st = pf + M * d * 4
+        D.mean1, D.rstd1, D.mean2, D.rstd2 = st, st + 4 * M, st + 8 * M, st + 12 * M
+        off = st + 16 * M
+        for i, ((seg, nseq, ml), sz) in enumerate(zip(launches, lse_sizes)):
+            D.seg[i], D.nseq[i], D.maxlen[i] = seg.data_ptr(), nseq, ml
+            D.lse_stride[i] = ((ml + 31) // 32) * 32
+            D.lse[i] = off
+            off += sz * 4
+        D.keymask = hip._p(pl.keymask)
+        D.eps = meta.eps
+        D.drop_thresh, D.inv_keep = meta.drop
+        D.attn_drop_thresh, D.attn_inv_keep = meta.attn_drop
+        D.seed = meta.seed & 0xFFFFFFFFFFFFFFFF
+        D.rs1, D.rs2 = hip._p(meta.rs1), hip._p(meta.rs2)
+        D.tile, D.need_bwd = meta.tile, int(need_bwd)
+        D.g1, D.g2, D.n1w, D.n1b, D.n2w, D.n2b = (t.data_ptr() for t in (g1, g2, n1w, n1b, n2w, n2b))
+        D.qkv_bias, D.proj_b = qkv_bias.data_ptr(), proj_b.data_ptr()
+        keep = [sb, sf, qkv_bias, pl]
+        w, wt = sh.get(qkv_w)
+        D.qkv_w, D.qkv_wT = w.data_ptr(), wt.data_ptr()
+        keep += [w, wt]
+        w, wt = sh.get(proj_w)
+        D.proj_w, D.proj_wT = w.data_ptr(), wt.data_ptr()
+        keep += [w, wt]
+        for i, (w1, b1, w2, b2) in enumerate(experts):
+            a, at = sh.get(w1)
+            c, ct = sh.get(w2)
+            D.w1[i], D.w1T[i], D.w2[i], D.w2T[i] = a.data_ptr(), at.data_ptr(), c.data_ptr(), ct.data_ptr()
+            D.b1[i], D.b2[i] = b1.data_ptr(), b2.data_ptr()
+            keep += [a, at, c, ct]
+        D.x, D.x2 = x.data_ptr(), x2.data_ptr()
+        hip.block_fwd(D)
         if need_bwd:
-            ctx.meta = meta
+            ctx.meta, ctx.desc, ctx.keep = meta, D, keep
             ctx.save_for_backward(x, *params)
-            ctx.saved = (y1, mean1, rstd1, qkv, ctxb, lses, zd1, x1, y2, mean2, rstd2, u, hh, zd2)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        meta = ctx.meta
+        meta, D = ctx.meta, ctx.desc
         x, *params = ctx.saved_tensors
-        (g1, g2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b) = params[:11]
-        experts = [params[11 + 4 * i: 15 + 4 * i] for i in range(len(meta.expert_ranges))]
-        (y1, mean1, rstd1, qkv, ctxb, lses, zd1, x1, y2, mean2, rstd2, u, hh, zd2) = ctx.saved
-        ctx.saved = None
-        pl, d, H, hid = meta.plan, meta.d, meta.heads, meta.hidden
+        nexp = len(meta.expert_ranges)
+        d, hid = meta.d, meta.hidden
         M, dev = x.shape[0], x.device
-        bf, f32 = torch.bfloat16, torch.float32
-        sh, seed = meta.shadows, meta.seed
+        f32 = torch.float32
         dx2 = dx2.contiguous()
         # every parameter gradient of this block lives in ONE zero-filled flat buffer (one memset)
-        nexp = len(meta.expert_ranges)
         total = 6 * d + 3 * d * d + d * d + d + 3 * d + nexp * (2 * hid * d + hid + d)
         flat = torch.zeros(total, dtype=f32, device=dev)
         off = [0]
@@ -229,48 +263,35 @@ class BlockFn(torch.autograd.Function):
             return t
 
         dg1, dg2, dn1w, dn1b, dn2w, dn2b = z(d), z(d), z(d), z(d), z(d), z(d)
-        dqkv_w, dproj_w, dproj_b = z(3 * d, d), z(d, d), z(d)
+        dqkv_w, dproj_w, dproj_b, dqkv_b = z(3 * d, d), z(d, d), z(d), z(3 * d)
+        D.dg1, D.dg2, D.dn1w, D.dn1b, D.dn2w, D.dn2b = (t.data_ptr() for t in (dg1, dg2, dn1w, dn1b, dn2w, dn2b))
+        D.dqkv_w, D.dproj_w, D.dproj_b, D.dqkv_b = (t.data_ptr() for t in (dqkv_w, dproj_w, dproj_b, dqkv_b))
         dexp = []
-        fork = _Fork(dev, OVERLAP_WGRAD)
-        # ---- FFN half
-        dz2 = _empty((M, d), bf, dev)
-        du = _empty((M, hid), bf, dev)
-        dy2 = _empty((M, d), bf, dev)
-        for ei, ((r0, n), (w1, b1, w2, b2)) in enumerate(zip(meta.expert_ranges, experts)):
+        for i in range(nexp):
             dw1, db1, dw2, db2 = z(hid, d), z(hid), z(d, hid), z(d)
-            sl = slice(r0, r0 + n)
-            hip.resid_bwd(dx2[sl], zd2[sl], g2, meta.rs2[sl] if meta.rs2 is not None else None, dz2[sl], dg2, db2,
-                          n, d, drop=meta.drop, seed=seed + 21 + 2 * ei)
-            hip.gemm_nt(hip.EPI_DGELU, dz2[sl], sh.get(w2)[1], n, hid, d, du[sl], aux=u[sl], drop=meta.drop,
-                        seed=seed + 20 + 2 * ei, tile=meta.tile)
-            with fork:      # off the critical path: dW2, db1, dW1
-                hip.gemm_tn(dz2[sl], hh[sl], dw2, n, d, hid)
-                hip.colsum(du[sl], db1, n, hid)
-                hip.gemm_tn(du[sl], y2[sl], dw1, n, hid, d)
-            hip.gemm_nt(hip.EPI_BIAS, du[sl], sh.get(w1)[1], n, d, hid, dy2[sl], tile=meta.tile)
+            D.dw1[i], D.db1[i], D.dw2[i], D.db2[i] = dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
             dexp += [dw1, db1, dw2, db2]
-        dx1 = _empty((M, d), f32, dev)
-        hip.ln_bwd(dy2, None, x1, n2w, mean2, rstd2, dx2, dx1, dn2w, dn2b, M, d)
-        # ---- attention half
-        dz1 = _empty((M, d), bf, dev)      # not aliased with dz2: the side stream may still read dz2
-        hip.resid_bwd(dx1, zd1, g1, meta.rs1, dz1, dg1, dproj_b, M, d, drop=meta.drop, seed=seed + 1)
-        dctx = dy2         # reuse: dy2 was consumed by ln_bwd above on this stream, never read on the side
-        hip.gemm_nt(hip.EPI_BIAS, dz1, sh.get(proj_w)[1], M, d, d, dctx, tile=meta.tile)
-        with fork:
-            hip.gemm_tn(dz1, ctxb, dproj_w, M, d, d)
-        dqkv = _empty((M, 3 * d), bf, dev)
-        for li, ((seg, nseq, maxlen), lse) in enumerate(zip(pl.attn_launches(meta.fused), lses)):
-            hip.attn_bwd(qkv, ctxb, dctx, lse, seg, nseq, pl.keymask, dqkv, H, d, maxlen, (d // H) ** -0.5,
-                         drop=meta.attn_drop, seed=seed + 11 + li)
-        dqkv_b = z(3 * d)
-        with fork:
-            hip.colsum(dqkv, dqkv_b, M, 3 * d)
-            hip.gemm_tn(dqkv, y1, dqkv_w, M, 3 * d, d)
-        dy1 = _empty((M, d), bf, dev)
-        hip.gemm_nt(hip.EPI_BIAS, dqkv, sh.get(qkv_w)[1], M, d, 3 * d, dy1, tile=meta.tile)
-        dx0 = _empty((M, d), f32, dev)
-        hip.ln_bwd(dy1, None, x, n1w, mean1, rstd1, dx1, dx0, dn1w, dn1b, M, d)
-        fork.join()        # gradients are complete (and every buffer the side stream read is free) from here
+        # temporaries: dz2 | du(4) | dy2(=dctx) | dz1 | dqkv(3) | dy1  bf16 ; dx1, dx0 fp32
+        tb = torch.empty(11 * M * d, dtype=torch.bfloat16, device=dev)
+        dx1 = torch.empty((M, d), dtype=f32, device=dev)
+        dx0 = torch.empty((M, d), dtype=f32, device=dev)
+        pb, md2 = tb.data_ptr(), M * d * 2
+        D.dz2, D.du, D.dy2, D.dz1, D.dqkv, D.dy1 = pb, pb + md2, pb + 5 * md2, pb + 6 * md2, pb + 7 * md2, pb + 10 * md2
+        D.dctx = D.dy2      # dy2 is consumed by ln_bwd on the main stream before dctx is written; never read on the side
+        D.dx2, D.dx1, D.dx0 = dx2.data_ptr(), dx1.data_ptr(), dx0.data_ptr()
+        ncols = max(3 * d, hid)
+        ws_main = hip.workspace(dev, ncols)
+        D.ws_main, D.ws_bytes = ws_main.data_ptr(), ws_main.numel() * 4
+        side = _side_stream(dev) if OVERLAP_WGRAD else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                ws_side = hip.workspace(dev, ncols)
+            D.ws_side, D.side_stream = ws_side.data_ptr(), side.cuda_stream
+            D.ws_bytes = min(D.ws_bytes, ws_side.numel() * 4)
+        else:
+            D.ws_side, D.side_stream = None, None
+        hip.block_bwd(D)
+        ctx.desc = ctx.keep = None
         grads = [dg1, dg2, dn1w, dn1b, dqkv_w, dqkv_b[:d], dqkv_b[2 * d:], dproj_w, dproj_b, dn2w, dn2b] + dexp
         return (dx0, None, *grads)
 

@@ -29,6 +29,31 @@ class Epilogue(ctypes.Structure):
                 ('seed', _u64)]
 
 
+_fp = _vp      # device pointers are passed as integers (tensor.data_ptr())
+
+
+class BlockDesc(ctypes.Structure):
+    """Mirror of VlmoBlockDesc (include/vlmo_hip.h); field order and types must match."""
+    _fields_ = (
+        [('M', _i32), ('d', _i32), ('hidden', _i32), ('heads', _i32),
+         ('n_experts', _i32), ('exp_row0', _i32 * 2), ('exp_rows', _i32 * 2),
+         ('n_attn', _i32), ('nseq', _i32 * 2), ('maxlen', _i32 * 2), ('lse_stride', _i32 * 2),
+         ('seg', _fp * 2), ('keymask', _fp), ('eps', _f32),
+         ('drop_thresh', _u32), ('attn_drop_thresh', _u32), ('inv_keep', _f32), ('attn_inv_keep', _f32),
+         ('seed', _u64), ('rs1', _fp), ('rs2', _fp), ('tile', _i32), ('need_bwd', _i32)]
+        + [(n, _fp) for n in ('g1', 'g2', 'n1w', 'n1b', 'n2w', 'n2b', 'qkv_bias', 'proj_b',
+                              'qkv_w', 'qkv_wT', 'proj_w', 'proj_wT')]
+        + [(n, _fp * 2) for n in ('b1', 'b2', 'w1', 'w1T', 'w2', 'w2T')]
+        + [(n, _fp) for n in ('x', 'x1', 'x2', 'y1', 'qkv', 'ctx', 'zd1', 'y2', 'u', 'h', 'zd2',
+                              'mean1', 'rstd1', 'mean2', 'rstd2')]
+        + [('lse', _fp * 2)]
+        + [(n, _fp) for n in ('dx2', 'dx1', 'dx0', 'dz2', 'du', 'dy2', 'dz1', 'dctx', 'dqkv', 'dy1',
+                              'dg1', 'dg2', 'dn1w', 'dn1b', 'dn2w', 'dn2b', 'dqkv_w', 'dqkv_b',
+                              'dproj_w', 'dproj_b')]
+        + [(n, _fp * 2) for n in ('dw1', 'db1', 'dw2', 'db2')]
+        + [('ws_main', _fp), ('ws_side', _fp), ('ws_bytes', _i64), ('side_stream', _fp)])
+
+
 _SIGS = {
     'vlmo_gemm_nt': [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32,
                      ctypes.POINTER(Epilogue), _vp],
@@ -54,6 +79,11 @@ _SIGS = {
     'vlmo_dvae_im2col': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'vlmo_maxpool2_nhwc': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'vlmo_argmax_reduce': [_vp, _i32, _vp, _i32, _vp],
+    'vlmo_block_fwd': [ctypes.POINTER(BlockDesc), _vp],
+    'vlmo_block_bwd': [ctypes.POINTER(BlockDesc), _vp],
+    'vlmo_profile_start': [_i32],
+    'vlmo_profile_stop': [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                          ctypes.POINTER(ctypes.c_int64)],
 }
 
 _lib = None
@@ -291,3 +321,37 @@ def maxpool2_nhwc(x, raw, relu, B, H, W, C):
 
 def argmax_reduce(partial, nchunk, ids, M):
     _check(lib().vlmo_argmax_reduce(_p(partial), nchunk, _p(ids), M, _stream()), 'vlmo_argmax_reduce')
+
+
+def block_fwd(desc):
+    _check(lib().vlmo_block_fwd(ctypes.byref(desc), _stream()), 'vlmo_block_fwd')
+
+
+def block_bwd(desc):
+    _check(lib().vlmo_block_bwd(ctypes.byref(desc), _stream()), 'vlmo_block_bwd')
+
+
+PROFILE_TAGS = 80
+
+
+def profile_start(max_records=1 << 15):
+    _check(lib().vlmo_profile_start(max_records), 'vlmo_profile_start')
+
+
+def profile_stop():
+    """-> {tag: (seconds, flops, launches)} for the launches recorded since profile_start()."""
+    n = PROFILE_TAGS
+    ms, fl, ln = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
+    lib().vlmo_profile_stop(n, ms, fl, ln)
+    names = {0: 'bias', 1: 'bias_gelu', 2: 'resid', 3: 'dgelu', 4: 'f32', 5: 'dual', 6: 'argmax'}
+    out = {}
+    for t in range(n):
+        if ln[t]:
+            if t == 64:
+                name = 'gemm_tn_kernel'
+            elif t >= 32:
+                name = f'conv_nt_kernel<{names.get(t - 32, t - 32)}>'
+            else:
+                name = f'gemm_nt_kernel<{names.get(t & 7, t & 7)},{"256x256" if t & 8 else "128x128"}>'
+            out[name] = (ms[t] * 1e-3, fl[t], ln[t])
+    return out

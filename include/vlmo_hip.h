@@ -146,6 +146,55 @@ int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, c
                        float* dln_b, float* dtype0, int B, int T, int d, uint32_t drop_thresh,
                        float inv_keep, uint64_t seed, hipStream_t stream);
 
+/* Optional timing of the GEMM launches with HIP event pairs on their launch stream (bench.py's roofline).
+ * stop() sums per tag: tag = epilogue id (+8 for the 256x256 tile) for vlmo_gemm_nt, 32 + epilogue for
+ * vlmo_conv2d_nhwc, 64 for vlmo_gemm_tn; returns the number of recorded launches. Synchronise first. */
+int vlmo_profile_start(int max_records);
+int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches);
+
+/* ---- one transformer Block in ONE call (vlmo.py:187-197 and its autograd) ---------------------
+ * Enqueues norm1 -> qkv -> attention -> proj(+gamma_1, residual) -> norm2 -> expert FFN(s)
+ * (+gamma_2, residual), resp. the whole backward of that, from native code: the host pays one
+ * FFI call per block instead of ~12 / ~30.  Expert e works on rows [exp_row0[e], +exp_rows[e]);
+ * attention launch a on seg[a] (sequences of at most maxlen[a] tokens).  All buffers caller-owned.
+ * Backward runs the weight-gradient GEMMs and bias column sums on `side_stream` (if not NULL)
+ * beside the input-gradient chain and joins before returning control of the buffers. */
+typedef struct VlmoBlockDesc {
+    int32_t M, d, hidden, heads;
+    int32_t n_experts, exp_row0[2], exp_rows[2];
+    int32_t n_attn, nseq[2], maxlen[2], lse_stride[2];
+    const int32_t* seg[2];
+    const int32_t* keymask;
+    float eps;
+    uint32_t drop_thresh, attn_drop_thresh;
+    float inv_keep, attn_inv_keep;
+    uint64_t seed;
+    const float* rs1;
+    const float* rs2;
+    int32_t tile, need_bwd;
+    /* parameters: fp32 vectors, bf16 shadow matrices W [out,in] and W^T [in,out] */
+    const float *g1, *g2, *n1w, *n1b, *n2w, *n2b, *qkv_bias, *proj_b;
+    const void *qkv_w, *qkv_wT, *proj_w, *proj_wT;
+    const float *b1[2], *b2[2];
+    const void *w1[2], *w1T[2], *w2[2], *w2T[2];
+    /* forward activations (saved for backward) */
+    const float* x;
+    float *x1, *x2;
+    void *y1, *qkv, *ctx, *zd1, *y2, *u, *h, *zd2;
+    float *mean1, *rstd1, *mean2, *rstd2, *lse[2];
+    /* backward */
+    const float* dx2;
+    float *dx1, *dx0;
+    void *dz2, *du, *dy2, *dz1, *dctx, *dqkv, *dy1;
+    float *dg1, *dg2, *dn1w, *dn1b, *dn2w, *dn2b, *dqkv_w, *dqkv_b, *dproj_w, *dproj_b;
+    float *dw1[2], *db1[2], *dw2[2], *db2[2];
+    float *ws_main, *ws_side;
+    int64_t ws_bytes;
+    hipStream_t side_stream;
+} VlmoBlockDesc;
+int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t stream);
+int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t stream);
+
 /* ---- dall_e dVAE encoder (dall_e/encoder.py:49-133), fp16 NHWC activations [B*H*W, C] ---- */
 
 /* Conv2d, stride 1, same padding (kw-1)/2 (dall_e/utils.py:37-48) as implicit GEMM:
