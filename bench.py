@@ -21,6 +21,8 @@ import sys
 import time
 from functools import partial
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # see exploremultimodal_amd/__init__.py
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -223,6 +225,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.preset)
         print(json.dumps(out), flush=True)
+    if reducer is not None:
+        reducer.close()
     if dist is not None:
         dist.destroy_process_group()
 

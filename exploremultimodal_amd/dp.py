@@ -22,6 +22,13 @@ Design (MI355X-first):
 `reduce_scatter=True` keeps only this rank's 1/W slice of every bucket reduced
 (ZeRO-2 gradient partition, ds_stage/l2.yaml) and exposes it as
 `bucket.shard`; the full gradient is then NOT written back.
+
+Transformer blocks of the HIP engine skip the pack step altogether: while a reducer
+is attached (engine.GRAD_SINK), BlockFn.backward accumulates its weight gradients
+straight into a persistent flat fp32 buffer owned by the reducer ("sink bucket"),
+p.grad are views of it, and the whole buffer is cast to bf16 and all-reduced as soon
+as the last backward call that contributes to it in this step has been enqueued.
+Only parameters outside the blocks (embeddings, final norm, heads) use the hook path.
 """
 import re
 
@@ -49,9 +56,24 @@ class _Bucket:
         self.used = []
 
 
+class _SinkBucket:
+    """Flat fp32 gradient storage of one engine block call signature (see module docstring)."""
+
+    def __init__(self, numel, device, comm_dtype, world):
+        self.numel = numel
+        self.padded = ((numel + world * 8 - 1) // (world * 8)) * (world * 8)
+        self.flat = torch.zeros(self.padded, dtype=torch.float32, device=device)
+        self.comm = self.flat if comm_dtype == torch.float32 else torch.empty(
+            self.padded, dtype=comm_dtype, device=device)
+        self.expected = 0       # backward calls still to come in this step
+        self.fresh = True       # zero before the first accumulation of the step
+        self.work = None
+        self.shard = None
+
+
 class GradReducer:
     def __init__(self, module, process_group=None, comm_dtype=torch.bfloat16, reduce_scatter=False,
-                 broadcast_params=True):
+                 broadcast_params=True, engine_sink=True):
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
         self.rank = dist.get_rank(self.pg)
@@ -79,8 +101,22 @@ class GradReducer:
                 p.register_post_accumulate_grad_hook(self._hook)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._armed = False
+        self.sinks = {}
+        self._sink_params = set()
+        if engine_sink and self.on_gpu:
+            from . import engine
+            engine.GRAD_SINK = self
         if broadcast_params and self.world > 1:
             self.sync_params(module)
+
+    def close(self):
+        """Detach from the engine (block gradients go back through autograd) and drop the buckets."""
+        from . import engine
+        if engine.GRAD_SINK is self:
+            engine.GRAD_SINK = None
+        self.sinks.clear()
+        self._sink_params.clear()
+        self._armed = False
 
     # ------------------------------------------------------------------ setup
     def sync_params(self, module):
@@ -110,10 +146,57 @@ class GradReducer:
             for nxt, _ in fn.next_functions:
                 stack.append(nxt)
         for b in self.buckets:
-            b.used = [p in used for p in b.params]
+            # parameters fed by an engine sink bucket never fire the accumulate hook
+            b.used = [(p in used) and (id(p) not in self._sink_params) for p in b.params]
             b.expected = b.pending = sum(b.used)
             b.work, b.launched = None, False
         self._armed = True
+
+    # ---- engine sink protocol (called from engine.BlockFn) -------------------------------------------
+    def expect(self, key):
+        sb = self.sinks.get(key)
+        if sb is not None:
+            sb.expected += 1
+        else:
+            self._pending_expect = getattr(self, '_pending_expect', {})
+            self._pending_expect[key] = self._pending_expect.get(key, 0) + 1
+
+    def acquire(self, key, numel, device):
+        sb = self.sinks.get(key)
+        if sb is None:
+            sb = _SinkBucket(numel, device, self.comm_dtype, self.world)
+            sb.expected = getattr(self, '_pending_expect', {}).pop(key, 1)
+            self.sinks[key] = sb
+            self._sink_params.update(key)
+        if sb.work is not None:         # previous step's reduction was never finish()ed: retire it first
+            sb.work.wait()
+            if self.on_gpu:
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            sb.work, sb.fresh = None, True
+        if sb.fresh:
+            sb.flat.zero_()
+            sb.fresh = False
+        return sb.flat[:numel]
+
+    def release(self, key):
+        sb = self.sinks[key]
+        sb.expected -= 1
+        if sb.expected <= 0:
+            self._launch_sink(sb)
+
+    def _launch_sink(self, sb):
+        if sb.comm is not sb.flat:
+            torch.mul(sb.flat, 1.0 / self.world, out=sb.comm)   # ONE pass: 1/world scaling + fp32 -> bf16 pack
+        else:
+            sb.flat.mul_(1.0 / self.world)
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.comm_stream):
+            if self.reduce_scatter:
+                sb.shard = torch.empty(sb.padded // self.world, dtype=sb.comm.dtype, device=self.device)
+                sb.work = dist.reduce_scatter_tensor(sb.shard, sb.comm, group=self.pg, async_op=True)
+            else:
+                sb.work = dist.all_reduce(sb.comm, group=self.pg, async_op=True)
 
     def _hook(self, p):
         if not self._armed:
@@ -161,8 +244,19 @@ class GradReducer:
             if not b.launched:        # a hook did not fire (grad was None): flush what we have
                 self._launch(b)
             b.work.wait()
+        for sb in self.sinks.values():
+            if sb.work is not None:
+                sb.work.wait()
         if self.on_gpu:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        for sb in self.sinks.values():
+            if sb.work is not None:
+                if self.reduce_scatter:
+                    sb.shard = sb.shard.float()
+                elif sb.comm is not sb.flat:
+                    sb.flat.copy_(sb.comm)               # ONE pass: bf16 -> fp32 unpack (already averaged)
+                sb.work = None
+            sb.fresh, sb.expected = True, 0
         for b in self.buckets:
             if b.expected == 0:
                 continue

@@ -16,6 +16,7 @@ import torch
 from . import hip
 
 LN_EPS = 1e-12          # vlmo_module.py:21-23
+GRAD_SINK = None         # set by dp.GradReducer: block gradients are accumulated straight into its flat buckets
 OVERLAP_WGRAD = True     # weight-gradient GEMMs + bias column sums on a side stream beside the dgrad chain
 DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
@@ -238,6 +239,10 @@ class BlockFn(torch.autograd.Function):
         if need_bwd:
             ctx.meta, ctx.desc, ctx.keep = meta, D, keep
             ctx.save_for_backward(x, *params)
+            ctx.sink = GRAD_SINK
+            if ctx.sink is not None:
+                ctx.sink_key = tuple(id(p) for p in params)
+                ctx.sink.expect(ctx.sink_key)
         return x2
 
     @staticmethod
@@ -251,7 +256,11 @@ class BlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         # every parameter gradient of this block lives in ONE zero-filled flat buffer (one memset)
         total = 6 * d + 3 * d * d + d * d + d + 3 * d + nexp * (2 * hid * d + hid + d)
-        flat = torch.zeros(total, dtype=f32, device=dev)
+        sink = ctx.sink
+        if sink is not None:    # data-parallel run: accumulate into the reducer's persistent flat bucket
+            flat = sink.acquire(ctx.sink_key, total, dev)
+        else:
+            flat = torch.zeros(total, dtype=f32, device=dev)
         off = [0]
 
         def z(*shape):
@@ -293,6 +302,17 @@ class BlockFn(torch.autograd.Function):
         hip.block_bwd(D)
         ctx.desc = ctx.keep = None
         grads = [dg1, dg2, dn1w, dn1b, dqkv_w, dqkv_b[:d], dqkv_b[2 * d:], dproj_w, dproj_b, dn2w, dn2b] + dexp
+        if sink is not None:
+            # the bucket IS the gradient storage: p.grad become views of it, autograd gets nothing to add
+            for p_, g_ in zip(params, grads):
+                if p_.requires_grad:
+                    if p_.grad is None:
+                        p_.grad = g_
+                    elif p_.grad.data_ptr() != g_.data_ptr():
+                        raise RuntimeError('a parameter of a data-parallel block already holds a foreign .grad; '
+                                           'use zero_grad(set_to_none=True)')
+            sink.release(ctx.sink_key)
+            return (dx0, None) + (None,) * len(grads)
         return (dx0, None, *grads)
 
 

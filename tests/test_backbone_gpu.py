@@ -153,6 +153,7 @@ def test_grad_reducer_rccl_single_rank():
     from exploremultimodal_amd.dp import GradReducer
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    red = None
     try:
         model, mc = build('mini')
         model.train()
@@ -176,4 +177,6 @@ def test_grad_reducer_rccl_single_rank():
         for n in want:
             assert torch.allclose(got[n], want[n], rtol=1e-2, atol=1e-2 * want[n].abs().max().item() + 1e-12), n
     finally:
+        if red is not None:
+            red.close()
         dist.destroy_process_group()
