@@ -61,6 +61,7 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.gamma = b->g1;
         e.resid = b->x;
         e.row_scale = b->rs1;
+        e.row_index = b->row_index;
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 1;
@@ -87,7 +88,8 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
         f.bias = b->b2[x];
         f.gamma = b->g2;
         f.resid = (const float*)bp((const void*)b->x1, r0, d, 4);
-        f.row_scale = b->rs2 ? b->rs2 + r0 : nullptr;
+        f.row_scale = b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr);
+        f.row_index = b->row_index ? b->row_index + r0 : nullptr;
         f.drop_thresh = b->drop_thresh;
         f.inv_keep = b->inv_keep;
         f.seed = b->seed + 21 + 2 * x;
@@ -112,8 +114,9 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     for (int x = 0; x < b->n_experts; ++x) {
         const size_t r0 = b->exp_row0[x];
         const int n = b->exp_rows[x];
-        TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2, b->rs2 ? b->rs2 + r0 : nullptr,
-                           bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d, b->drop_thresh, b->inv_keep,
+        TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2,
+                           b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr),
+                           b->row_index ? b->row_index + r0 : nullptr, bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d, b->drop_thresh, b->inv_keep,
                            b->seed + 21 + 2 * x, b->ws_main, b->ws_bytes, st));
         VlmoEpilogue e = epi();
         e.out = bp(b->du, r0, hid, 2);
@@ -136,7 +139,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     TRY(vlmo_ln_bwd(b->dy2, 0, nullptr, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, M, d,
                     b->ws_main, b->ws_bytes, st));
     // ---- attention half
-    TRY(vlmo_resid_bwd(b->dx1, b->zd1, b->g1, b->rs1, b->dz1, b->dg1, b->dproj_b, M, d, b->drop_thresh, b->inv_keep,
+    TRY(vlmo_resid_bwd(b->dx1, b->zd1, b->g1, b->rs1, b->row_index, b->dz1, b->dg1, b->dproj_b, M, d, b->drop_thresh, b->inv_keep,
                        b->seed + 1, b->ws_main, b->ws_bytes, st));
     {
         VlmoEpilogue e = epi();

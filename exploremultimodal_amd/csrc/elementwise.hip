@@ -60,7 +60,8 @@ template <> __device__ __forceinline__ void st4<f16>(f16* p, f32x4 v) {
 // two rows in flight per thread (independent loads) for memory-level parallelism
 __global__ void resid_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ zd,
                                  const float* __restrict__ gamma, const float* __restrict__ row_scale,
-                                 bf16* __restrict__ dz, float* __restrict__ ws, bool need_gamma, int M,
+                                 const int32_t* __restrict__ row_index, bf16* __restrict__ dz,
+                                 float* __restrict__ ws, bool need_gamma, int M,
                                  int d, int rows_per_block, uint32_t thresh, float inv_keep, uint64_t seed) {
     extern __shared__ float red[];   // [RY][2][d]
     const int c4 = threadIdx.x * 4, RY = blockDim.y;
@@ -78,7 +79,8 @@ __global__ void resid_bwd_kernel(const float* __restrict__ dx, const bf16* __res
             const size_t o = (size_t)(ok[k] ? m : mb) * d + c4;
             gx[k] = *(const f32x4*)(dx + o);
             z[k] = need_gamma ? ld4<bf16>(zd + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rs[k] = row_scale ? row_scale[ok[k] ? m : mb] : 1.f;
+            const int mr = ok[k] ? m : mb;
+            rs[k] = row_scale ? row_scale[row_index ? row_index[mr] : mr] : 1.f;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -403,8 +405,9 @@ int rows_per_block_for(int M, int target_blocks, int mult) {
 
 }  // namespace
 
-extern "C" int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const float* row_scale, void* dz,
-                              float* dgamma, float* dbias, int M, int d, uint32_t drop_thresh, float inv_keep,
+extern "C" int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const float* row_scale,
+                              const int32_t* row_index, void* dz, float* dgamma, float* dbias, int M, int d,
+                              uint32_t drop_thresh, float inv_keep,
                               uint64_t seed, float* ws, int64_t ws_bytes, hipStream_t stream) {
     VLMO_CHECK_ARG(dx && dz, "vlmo_resid_bwd: null pointer");
     VLMO_CHECK_ARG(!dgamma || zd, "vlmo_resid_bwd: dgamma needs zd");
@@ -418,7 +421,7 @@ extern "C" int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamm
     const int rpb = rows_per_block_for(M, VLMO_MAX_PARTIAL_BLOCKS, ry * 2);
     const int grid = (M + rpb - 1) / rpb;
     hipLaunchKernelGGL(resid_bwd_kernel, dim3(grid), dim3(tx, ry), ry * 2 * d * sizeof(float), stream, dx,
-                       (const bf16*)zd, gamma, row_scale, (bf16*)dz, ws, dgamma != nullptr, M, d, rpb, drop_thresh,
+                       (const bf16*)zd, gamma, row_scale, row_index, (bf16*)dz, ws, dgamma != nullptr, M, d, rpb, drop_thresh,
                        inv_keep, seed);
     VLMO_CHECK_LAUNCH("vlmo_resid_bwd");
     if (dgamma || dbias) return reduce_partials(ws, grid, 2 * d, dgamma, d, dbias, stream);

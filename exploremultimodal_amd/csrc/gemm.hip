@@ -145,8 +145,8 @@ template <int BK> __device__ __forceinline__ int nt_swz(int row) {
     return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK>
-__global__ __launch_bounds__(WM * WN * 64, (BK == 32 && WM * WN == 4) ? 4 : 2) void gemm_nt_kernel(const GemmNT p) {
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK, int NSTG>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p) {
     typedef typename Elem<T>::v8 v8;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BK == 32 && WM * WN == 4) ? 4 : 2) v
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = BM / SRPI / NW, NB = BN / SRPI / NW;
     static_assert(BM % (SRPI * NW) == 0 && BN % (SRPI * NW) == 0, "tile/wave mismatch");
-    static_assert(NW * 32 * TN * 32 * 4 <= 2 * STAGE, "epilogue LDS must fit in the ring");
+    static_assert(NW * 32 * TN * 32 * 4 <= NSTG * STAGE, "epilogue LDS must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -228,15 +228,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BK == 32 && WM * WN == 4) ? 4 : 2) v
 #pragma unroll
         for (int i = 0; i < NB; ++i) glds16(b_src[i] + kt * BK, s + A_BYTES + (i * NW + wave) * 1024);
     };
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* s = smem + (kt & 1) * STAGE;
-        // all 4 k-substeps' fragments are requested up front (64 VGPRs) so the LDS latency of
-        // substep s+1.. hides under the MFMAs of substep s (hipcc otherwise emits
-        // read4 -> lgkmcnt(0) -> mfma4 -> read4 ..., measured: LDS phase + MFMA phase serialised)
+    auto compute = [&](const char* s) {
         v8 af[KS][TM], bf[KS][TN];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -252,6 +244,36 @@ __global__ __launch_bounds__(WM * WN * 64, (BK == 32 && WM * WN == 4) ? 4 : 2) v
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
+    };
+    if constexpr (NSTG == 2) {
+        // 2-deep ring: one K-tile in flight behind the one being multiplied
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            compute(smem + (kt & 1) * STAGE);
+        }
+    } else {
+        // NSTG-deep ring, NSTG-1 K-tiles in flight: counted vmcnt + raw s_barrier so the LDS-DMA of the
+        // younger tiles stays in flight across the barrier (a __syncthreads() would drain it)
+        constexpr int LPS = NA + NB;      // LDS-DMA instructions per wave per K-tile
+#pragma unroll
+        for (int q = 0; q < NSTG - 1; ++q)
+            if (q < nk) stage(q, q);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int younger = min(NSTG - 2, nk - 1 - kt);     // K-tiles issued after tile kt
+            if (younger >= 2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            } else if (younger == 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + NSTG - 1 < nk) stage((kt + NSTG - 1) % NSTG, kt + NSTG - 1);
+            compute(smem + (kt % NSTG) * STAGE);
+        }
     }
 
     // ---- epilogue: accumulators -> wave-private LDS -> full-row segments ----
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BK == 32 && WM * WN == 4) ? 4 : 2) v
         for (int it = 0; it < NIT; ++it) {
             const int gmc = min(m0 + wm * (BM / WM) + i * 32 + it * RPI + rrow, p.M - 1);
             ext[it] = epilogue_ext<T, EPI>(p, gmc, gnc);
-            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[gmc] : 1.f;
+            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[p.e.row_index ? p.e.row_index[gmc] : gmc] : 1.f;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -451,14 +473,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV = false, int BK = 64>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV = false, int BK = 64, int NSTG = 2>
 int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    constexpr int LDS = NSTG * (BM + BN) * BK * 2;
     dim3 grid(tiles), block(WM * WN * 64);
 #define VLMO_LAUNCH_EPI(E)                                                                     \
     case E: {                                                                                  \
-        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV, BK>;                                         \
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV, BK, NSTG>;                                         \
         if (LDS > 65536) {                                                                     \
             static bool attr_set = false;                                                      \
             if (!attr_set) {                                                                   \
@@ -596,7 +618,7 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
         return launch_nt<f16, 128, 128, 2, 2>(epi, p, stream);
     }
     if (tile == 1) return launch_nt<bf16, 256, 128, 4, 2>(epi, p, stream);
-    if (tile == 2) return launch_nt<bf16, 128, 128, 2, 2, false, 32>(epi, p, stream);
+    if (tile == 2) return launch_nt<bf16, 128, 128, 2, 2, false, 32, 4>(epi, p, stream);
     if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
 }

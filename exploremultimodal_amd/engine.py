@@ -41,6 +41,16 @@ class ShadowCache:
             self._c[key] = ent
         return ent[1], ent[2]
 
+    def qkv_bias(self, q_bias, v_bias):
+        """cat(q_bias, 0, v_bias) (vlmo.py:72-75), cached until either parameter changes."""
+        key = ('qkvb', id(q_bias))
+        ver = (q_bias._version, v_bias._version, q_bias.data_ptr())
+        ent = self._c.get(key)
+        if ent is None or ent[0] != ver:
+            ent = (ver, torch.cat([q_bias.detach(), torch.zeros_like(q_bias), v_bias.detach()]))
+            self._c[key] = ent
+        return ent[1]
+
     def clear(self):
         self._c.clear()
 
@@ -76,9 +86,10 @@ class _PlanStatic:
         rm_t = (torch.arange(B).view(B, 1) * N + torch.arange(T).view(1, T)).reshape(-1)
         rm_i = (torch.arange(B).view(B, 1) * N + T + torch.arange(P).view(1, P)).reshape(-1)
         self.rowmap = torch.cat([rm_t, rm_i]).to(torch.int32).to(device)
-        # sample index of every packed row (drop-path scale expansion)
-        self.row_sample_txt = torch.arange(B).repeat_interleave(T).to(device) if T else None
-        self.row_sample_img = torch.arange(B).repeat_interleave(P).to(device) if P else None
+        # drop-path group of every packed row: text rows of sample b -> b, image rows -> B + b (a per-sample
+        # scale vector [2B] is expanded inside the kernels through this map)
+        self.row_group = torch.cat([torch.arange(B).repeat_interleave(T),
+                                    B + torch.arange(B).repeat_interleave(P)]).to(torch.int32).to(device)
 
 
 class Plan:
@@ -91,7 +102,7 @@ class Plan:
         self.device = device
         st = _PlanStatic.get(B, T, P, device)
         self.seg_txt, self.seg_img, self.seg_vl = st.seg_txt, st.seg_img, st.seg_vl
-        self.rowmap, self.row_sample_txt, self.row_sample_img = st.rowmap, st.row_sample_txt, st.row_sample_img
+        self.rowmap, self.row_group = st.rowmap, st.row_group
         # key-padding mask over packed rows (vlmo.py:89-91); None = all valid
         parts = []
         if T:
@@ -192,7 +203,7 @@ class BlockFn(torch.autograd.Function):
         sb = torch.empty(16 * M * d, dtype=torch.bfloat16, device=dev)
         sf = torch.empty(M * d + 4 * M + sum(lse_sizes), dtype=torch.float32, device=dev)
         x2 = torch.empty((M, d), dtype=torch.float32, device=dev)
-        qkv_bias = torch.cat([q_bias.detach(), torch.zeros_like(q_bias), v_bias.detach()])   # vlmo.py:72-75
+        qkv_bias = sh.qkv_bias(q_bias, v_bias)
         D = hip.BlockDesc()
         D.M, D.d, D.hidden, D.heads = M, d, hid, H
         D.n_experts = nexp
@@ -218,6 +229,7 @@ class BlockFn(torch.autograd.Function):
         D.attn_drop_thresh, D.attn_inv_keep = meta.attn_drop
         D.seed = meta.seed & 0xFFFFFFFFFFFFFFFF
         D.rs1, D.rs2 = hip._p(meta.rs1), hip._p(meta.rs2)
+        D.row_index = pl.row_group.data_ptr() if meta.rs1 is not None else None
         D.tile, D.need_bwd = meta.tile, int(need_bwd)
         D.g1, D.g2, D.n1w, D.n1b, D.n2w, D.n2b = (t.data_ptr() for t in (g1, g2, n1w, n1b, n2w, n2b))
         D.qkv_bias, D.proj_b = qkv_bias.data_ptr(), proj_b.data_ptr()

@@ -23,7 +23,7 @@ _vp, _i32, _u32, _u64, _f32, _i64 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_u
 
 class Epilogue(ctypes.Structure):
     _fields_ = [('out', _vp), ('out2', _vp), ('bias', _vp), ('gamma', _vp),
-                ('resid', _vp), ('row_scale', _vp), ('aux', _vp),
+                ('resid', _vp), ('row_scale', _vp), ('row_index', _vp), ('aux', _vp),
                 ('ldo', _i32), ('ld2', _i32), ('relu', _i32),
                 ('drop_thresh', _u32), ('inv_keep', _f32), ('beta', _f32),
                 ('seed', _u64)]
@@ -40,7 +40,7 @@ class BlockDesc(ctypes.Structure):
          ('n_attn', _i32), ('nseq', _i32 * 2), ('maxlen', _i32 * 2), ('lse_stride', _i32 * 2),
          ('seg', _fp * 2), ('keymask', _fp), ('eps', _f32),
          ('drop_thresh', _u32), ('attn_drop_thresh', _u32), ('inv_keep', _f32), ('attn_inv_keep', _f32),
-         ('seed', _u64), ('rs1', _fp), ('rs2', _fp), ('tile', _i32), ('need_bwd', _i32)]
+         ('seed', _u64), ('rs1', _fp), ('rs2', _fp), ('row_index', _fp), ('tile', _i32), ('need_bwd', _i32)]
         + [(n, _fp) for n in ('g1', 'g2', 'n1w', 'n1b', 'n2w', 'n2b', 'qkv_bias', 'proj_b',
                               'qkv_w', 'qkv_wT', 'proj_w', 'proj_wT')]
         + [(n, _fp * 2) for n in ('b1', 'b2', 'w1', 'w1T', 'w2', 'w2T')]
@@ -64,7 +64,7 @@ _SIGS = {
                       _u64, _vp],
     'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f32,
                       _u32, _f32, _u64, _vp],
-    'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp, _i64, _vp],
+    'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp, _i64, _vp],
     'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp],
     'vlmo_cast_weight': [_i32, _vp, _i32, _i32, _vp, _vp, _vp],
     'vlmo_patchify': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -161,9 +161,9 @@ def drop_params(p, training):
 # ------------------------------------------------------------------ wrappers
 
 def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=None,
-            row_scale=None, aux=None, ldo=None, ld2=None, relu=False, drop=(0, 1.0), seed=0,
+            row_scale=None, row_index=None, aux=None, ldo=None, ld2=None, relu=False, drop=(0, 1.0), seed=0,
             beta=0.0, tile=-1, lda=None, ldb=None):
-    e = Epilogue(_p(out), _p(out2), _p(bias), _p(gamma), _p(resid), _p(row_scale), _p(aux),
+    e = Epilogue(_p(out), _p(out2), _p(bias), _p(gamma), _p(resid), _p(row_scale), _p(row_index), _p(aux),
                  ldo if ldo is not None else out.stride(0),
                  ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else
                                               (aux.stride(0) if aux is not None else 0)),
@@ -222,9 +222,9 @@ def attn_bwd(qkv, ctx, dctx, lse, seg, nseq, keymask, dqkv, heads, d, max_len, s
     _check(rc, 'vlmo_attn_bwd')
 
 
-def resid_bwd(dx, zd, gamma, row_scale, dz, dgamma, dbias, M, d, drop=(0, 1.0), seed=0):
+def resid_bwd(dx, zd, gamma, row_scale, dz, dgamma, dbias, M, d, drop=(0, 1.0), seed=0, row_index=None):
     ws = workspace(dx.device, 2 * d)
-    rc = lib().vlmo_resid_bwd(_p(dx), _p(zd), _p(gamma), _p(row_scale), _p(dz), _p(dgamma),
+    rc = lib().vlmo_resid_bwd(_p(dx), _p(zd), _p(gamma), _p(row_scale), _p(row_index), _p(dz), _p(dgamma),
                               _p(dbias), M, d, drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF,
                               _p(ws), ws.numel() * 4, _stream())
     _check(rc, 'vlmo_resid_bwd')
@@ -295,7 +295,7 @@ def zero_page(device):
 
 def conv2d_nhwc(epi, x, B, H, W, Cin, kw, w, Cout, out, *, out2=None, bias=None, resid=None, relu=False,
                 beta=0.0, ldo=None):
-    e = Epilogue(_p(out), _p(out2), _p(bias), None, _p(resid), None, None,
+    e = Epilogue(_p(out), _p(out2), _p(bias), None, _p(resid), None, None, None,
                  ldo if ldo is not None else out.stride(0), out2.stride(0) if out2 is not None else 0,
                  int(relu), 0, 1.0, beta, 0)
     ev = None

@@ -134,30 +134,19 @@ class Block(nn.Module):
             ps += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
         return ps
 
-    def _drop_path_scale(self, B):
-        """timm DropPath: per-sample Bernoulli(1-p)/(1-p) in training mode, else None."""
-        if not self.training or self.drop_path_rate <= 0.0:
-            return None
-        keep = 1.0 - self.drop_path_rate
-        dev = self.gamma_1.device
-        return torch.empty(B, device=dev).bernoulli_(keep).div_(keep)
-
     def run(self, x, plan, routes, ranges, fused, shadows, seed):
         """x: packed fp32 [M, d]; routes/ranges: experts and their row ranges."""
         rs1 = rs2 = None
         if self.training and self.drop_path_rate > 0.0:
-            def expand():
-                parts = []
-                # the reference calls the block once per modality below the fusion layer, so each
-                # stream draws its own per-sample mask (vlmo.py:402-404)
-                if plan.T:
-                    st = self._drop_path_scale(plan.B)
-                    parts.append(st[plan.row_sample_txt])
-                if plan.P:
-                    si = st if (fused and plan.T) else self._drop_path_scale(plan.B)
-                    parts.append(si[plan.row_sample_img])
-                return torch.cat(parts).contiguous()
-            rs1, rs2 = expand(), expand()
+            # timm DropPath: per-sample Bernoulli(keep)/keep, one draw per residual branch.  Below the fusion
+            # layer the reference calls the block once per modality (vlmo.py:402-404), so the text and image
+            # streams of a sample draw independently; above it the fused sequence shares one draw.
+            # Layout [branch, stream, B]; rows find their entry through plan.row_group inside the kernels.
+            keep = 1.0 - self.drop_path_rate
+            sc = torch.empty((2, 2, plan.B), device=x.device).bernoulli_(keep).div_(keep)
+            if fused or not (plan.T and plan.P):
+                sc[:, 1 if plan.T else 0] = sc[:, 0 if plan.T else 1]
+            rs1, rs2 = sc[0].reshape(-1), sc[1].reshape(-1)
         meta = engine.BlockMeta(plan, self.num_heads, self.dim, self.mlp_hidden_dim, fused, ranges, self.training,
                                 self.drop, self.attn.attn_drop, rs1, rs2, seed, eps=self.norm1.eps)
         meta.shadows = shadows

@@ -53,7 +53,9 @@ typedef struct VlmoEpilogue {
     const float* bias;      /* [N] or NULL                                  */
     const float* gamma;     /* [N] layer-scale or NULL (=1)                 */
     const float* resid;     /* [M, ldo] fp32 residual stream                */
-    const float* row_scale; /* [M] drop-path scale per token or NULL (=1)   */
+    const float* row_scale; /* drop-path scale: per token [M], or per group */
+                            /* when row_index is set (scale[row_index[m]])  */
+    const int32_t* row_index; /* [M] token -> scale group, or NULL          */
     const void* aux;        /* [M, ld2] pre-activation for VLMO_EPI_DGELU   */
     int32_t ldo, ld2;
     int32_t relu;
@@ -110,7 +112,8 @@ int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const floa
 /* Residual-branch backward (vlmo.py:194-196): dz = dx * gamma * row_scale * dropmask/(1-p);
  * dgamma += sum_m dx * row_scale * zd;  dbias += sum_m dz. */
 int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const float* row_scale,
-                   void* dz, float* dgamma, float* dbias, int M, int d, uint32_t drop_thresh,
+                   const int32_t* row_index, void* dz, float* dgamma, float* dbias, int M, int d,
+                   uint32_t drop_thresh,
                    float inv_keep, uint64_t seed, float* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* out[c] += sum_m x[m, c]  (bias gradients), x is bf16/f16 [M, ld]. */
@@ -169,8 +172,9 @@ typedef struct VlmoBlockDesc {
     uint32_t drop_thresh, attn_drop_thresh;
     float inv_keep, attn_inv_keep;
     uint64_t seed;
-    const float* rs1;
-    const float* rs2;
+    const float* rs1;           /* drop-path scales of the two residual branches: per row, or per */
+    const float* rs2;           /* group when row_index is set                                     */
+    const int32_t* row_index;
     int32_t tile, need_bwd;
     /* parameters: fp32 vectors, bf16 shadow matrices W [out,in] and W^T [in,out] */
     const float *g1, *g2, *n1w, *n1b, *n2w, *n2b, *qkv_bias, *proj_b;
