@@ -128,9 +128,9 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.seed = b->seed + 20 + 2 * x;
         TRY(vlmo_gemm_nt(VLMO_EPI_DGELU, VLMO_BF16, b->tile, bp(b->dz2, r0, d, 2), d, b->w2T[x], d, n, hid, d, &e, st));
         fork();
-        TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid, 1.f, 0, side));
+        TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
         TRY(vlmo_colsum(VLMO_BF16, bp(b->du, r0, hid, 2), hid, b->db1[x], n, hid, ws_side, b->ws_bytes, side));
-        TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d, 1.f, 0, side));
+        TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
         VlmoEpilogue f = epi();
         f.out = bp(b->dy2, r0, d, 2);
         f.ldo = d;
@@ -148,7 +148,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dz1, d, b->proj_wT, d, M, d, d, &e, st));
     }
     fork();
-    TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, side));
+    TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     const float scale = 1.0f / sqrtf((float)(d / b->heads));
     for (int a = 0; a < b->n_attn; ++a)
         TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
@@ -156,7 +156,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
                           b->seed + 11 + a, st));
     fork();
     TRY(vlmo_colsum(VLMO_BF16, b->dqkv, 3 * d, b->dqkv_b, M, 3 * d, ws_side, b->ws_bytes, side));
-    TRY(vlmo_gemm_tn(VLMO_BF16, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d, 1.f, 0, side));
+    TRY(vlmo_gemm_tn(VLMO_BF16, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     {
         VlmoEpilogue e = epi();
         e.out = b->dy1;

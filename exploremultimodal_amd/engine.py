@@ -304,13 +304,17 @@ class BlockFn(torch.autograd.Function):
         ws_main = hip.workspace(dev, ncols)
         D.ws_main, D.ws_bytes = ws_main.data_ptr(), ws_main.numel() * 4
         side = _side_stream(dev) if OVERLAP_WGRAD else None
+        tn_need = hip.lib().vlmo_gemm_tn_ws_bytes(M, hid, d)
         if side is not None:
             with torch.cuda.stream(side):
                 ws_side = hip.workspace(dev, ncols)
+                ws_tn = hip.tn_workspace(dev, tn_need)
             D.ws_side, D.side_stream = ws_side.data_ptr(), side.cuda_stream
             D.ws_bytes = min(D.ws_bytes, ws_side.numel() * 4)
         else:
             D.ws_side, D.side_stream = None, None
+            ws_tn = hip.tn_workspace(dev, tn_need)
+        D.ws_tn, D.ws_tn_bytes = ws_tn.data_ptr(), ws_tn.numel() * 4
         hip.block_bwd(D)
         ctx.desc = ctx.keep = None
         grads = [dg1, dg2, dn1w, dn1b, dqkv_w, dqkv_b[:d], dqkv_b[2 * d:], dproj_w, dproj_b, dn2w, dn2b] + dexp

@@ -51,13 +51,14 @@ class BlockDesc(ctypes.Structure):
                               'dg1', 'dg2', 'dn1w', 'dn1b', 'dn2w', 'dn2b', 'dqkv_w', 'dqkv_b',
                               'dproj_w', 'dproj_b')]
         + [(n, _fp * 2) for n in ('dw1', 'db1', 'dw2', 'db2')]
-        + [('ws_main', _fp), ('ws_side', _fp), ('ws_bytes', _i64), ('side_stream', _fp)])
+        + [('ws_main', _fp), ('ws_side', _fp), ('ws_bytes', _i64), ('ws_tn', _fp), ('ws_tn_bytes', _i64),
+           ('side_stream', _fp)])
 
 
 _SIGS = {
     'vlmo_gemm_nt': [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32,
                      ctypes.POINTER(Epilogue), _vp],
-    'vlmo_gemm_tn': [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    'vlmo_gemm_tn': [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp],
     'vlmo_ln_fwd': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
     'vlmo_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp],
     'vlmo_attn_fwd': [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _f32,
@@ -106,6 +107,8 @@ def lib():
         L.vlmo_abi_version.restype = ctypes.c_int
         L.vlmo_reduce_ws_bytes.restype = ctypes.c_int64
         L.vlmo_reduce_ws_bytes.argtypes = [_i32]
+        L.vlmo_gemm_tn_ws_bytes.restype = ctypes.c_int64
+        L.vlmo_gemm_tn_ws_bytes.argtypes = [_i32, _i32, _i32]
         for name, sig in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = sig
@@ -115,7 +118,7 @@ def lib():
 
 
 def exported_symbols():
-    return ['vlmo_last_error', 'vlmo_abi_version', 'vlmo_reduce_ws_bytes'] + list(_SIGS)
+    return ['vlmo_last_error', 'vlmo_abi_version', 'vlmo_reduce_ws_bytes', 'vlmo_gemm_tn_ws_bytes'] + list(_SIGS)
 
 
 def _check(rc, name):
@@ -181,13 +184,28 @@ def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=
     _check(rc, 'vlmo_gemm_nt')
 
 
-def gemm_tn(A, B, C, M, N1, N2, alpha=1.0, splits=0):
+_WS_TN = {}
+
+
+def tn_workspace(device, nbytes):
+    """Persistent slab scratch of the weight-gradient GEMM, one per (device, stream)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS_TN.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 24) // 4, dtype=torch.float32, device=device)
+        _WS_TN[key] = ws
+    return ws
+
+
+def gemm_tn(A, B, C, M, N1, N2, alpha=1.0, splits=0, slab=True):
     ev = None
     if PROFILE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
+    ws = tn_workspace(A.device, max(splits, 16) * N1 * N2 * 4 if splits > 0 else
+                      lib().vlmo_gemm_tn_ws_bytes(M, N1, N2)) if slab else None
     rc = lib().vlmo_gemm_tn(_dt(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(C), C.stride(0),
-                            M, N1, N2, alpha, splits, _stream())
+                            M, N1, N2, alpha, splits, _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
     if ev is not None:
         ev[1].record()
         PROFILE.setdefault(('gemm_tn_kernel', 2 * M * N1 * N2), []).append(ev)

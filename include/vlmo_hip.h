@@ -76,10 +76,14 @@ int vlmo_abi_version(void);
 int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
                  int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream);
 
-/* C[N1,N2] += alpha * A[M,N1]^T . B[M,N2]  (fp32 atomic accumulation; weight
- * gradients of the linears above, i.e. autograd of vlmo.py:76-78,96,195-196). */
+/* C[N1,N2] += alpha * A[M,N1]^T . B[M,N2]  (weight gradients of the linears above, i.e. autograd of
+ * vlmo.py:76-78,96,195-196).  The token dimension is split over workgroups; partial products go through
+ * the caller's workspace `ws` (>= vlmo_gemm_tn_ws_bytes(M,N1,N2)) and one reduction pass, or, with
+ * ws = NULL, straight into C with fp32 atomics. */
+int64_t vlmo_gemm_tn_ws_bytes(int M, int N1, int N2);
 int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
-                 int M, int N1, int N2, float alpha, int splits, hipStream_t stream);
+                 int M, int N1, int N2, float alpha, int splits, float* ws, int64_t ws_bytes,
+                 hipStream_t stream);
 
 /* LayerNorm over the last dim (eps = 1e-12 in VLMo: vlmo_module.py:21-23; vlmo.py:188,192,413).
  * x fp32 [M,d] -> y (bf16, or fp32 when out_f32) at row rowmap[m] (or m), + mean/rstd [M]. */
@@ -192,8 +196,10 @@ typedef struct VlmoBlockDesc {
     void *dz2, *du, *dy2, *dz1, *dctx, *dqkv, *dy1;
     float *dg1, *dg2, *dn1w, *dn1b, *dn2w, *dn2b, *dqkv_w, *dqkv_b, *dproj_w, *dproj_b;
     float *dw1[2], *db1[2], *dw2[2], *db2[2];
-    float *ws_main, *ws_side;
+    float *ws_main, *ws_side;   /* column-reduction scratch per stream (vlmo_reduce_ws_bytes)            */
     int64_t ws_bytes;
+    float* ws_tn;               /* weight-gradient slab scratch (vlmo_gemm_tn_ws_bytes), used on the     */
+    int64_t ws_tn_bytes;        /* side stream; NULL = atomics                                           */
     hipStream_t side_stream;
 } VlmoBlockDesc;
 int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t stream);

@@ -132,6 +132,8 @@ def test_gemm_tn_wgrad(M, N1, N2):
     _close(C, ref, 2e-3, 2e-3 * math.sqrt(M), 'wgrad')
     hip.gemm_tn(A, B, C, M, N1, N2, alpha=0.5, splits=3)
     _close(C, 1.5 * ref, 2e-3, 3e-3 * math.sqrt(M), 'wgrad accumulate')
+    hip.gemm_tn(A, B, C, M, N1, N2, alpha=-1.5, splits=3, slab=False)      # atomic path
+    _close(C, 0 * ref, 2e-3, 6e-3 * math.sqrt(M), 'wgrad atomics')
 
 
 def test_gemm_tn_exact_integers():

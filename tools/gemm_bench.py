@@ -54,6 +54,7 @@ for name, N1, N2 in [('wgrad_fc1', 3072, 768), ('wgrad_fc2', 768, 3072), ('wgrad
     A = torch.randn(M, N1, device=dev).bfloat16()
     B = torch.randn(M, N2, device=dev).bfloat16()
     C = torch.zeros(N1, N2, device=dev)
-    for splits in (0, 2, 4, 8, 16):
-        t = timeit(lambda: hip.gemm_tn(A, B, C, M, N1, N2, splits=splits), args.reps)
-        print(f'tn {name:11s} M={M} N1={N1:5d} N2={N2:5d} splits={splits:2d}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s', flush=True)
+    for splits in (0, 4, 8):
+        for slab in (True, False):
+            t = timeit(lambda: hip.gemm_tn(A, B, C, M, N1, N2, splits=splits, slab=slab), args.reps)
+            print(f'tn {name:11s} M={M} N1={N1:5d} N2={N2:5d} splits={splits:2d} slab={int(slab)}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s', flush=True)
