@@ -216,8 +216,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
 
 // ------------------------------------------------------------------ backward
 // Two phases in one launch, sharing the Q/K/V/dO LDS images:
-//   phase 1: a wavefront owns 32 queries, sweeps key tiles  -> dQ   (no reduction across waves)
-//   phase 2: a wavefront owns 32 keys,    sweeps query tiles -> dK, dV
+//   dQ item   : a wavefront owns 32 queries, sweeps key tiles   -> dQ  (no reduction across waves)
+//   dK/dV item: a wavefront owns 32 keys,    sweeps query tiles -> dK, dV
+// The 2*nq items are independent once the images are staged, so the 8 waves pull them from one LDS
+// work counter, longest (dK/dV) first: 9+9 items at N=261 finish in ~40 units of work per wave instead of
+// the 56 of two statically scheduled phases (9 tiles over 8 waves = two rounds each).
 // P is recomputed from the forward's log-sum-exp; delta = rowsum(dO * O).
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, const int NPAD) {
     const int IMG = NPAD * 128;
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     float* lseq = kbias + NPAD;    // log2-domain LSE per query (+inf on padded queries)
     float* delta = lseq + NPAD;
     int* rowidx = (int*)(delta + NPAD);
+    int* next_item = rowidx + NPAD;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     const int ld = 3 * a.d;
     int N;
     setup_rows(a.seg, sidx, a.keymask, NPAD, rowidx, kbias, N);
+    if (threadIdx.x == 0) *next_item = 0;
     __syncthreads();
     const int nq = (N + 31) >> 5;   // query tiles == key tiles (self-attention)
     stage_image<8>(a.qkv, ld, hd * 64, rowidx, Qimg, nq * 4, wave, lane);
@@ -264,8 +269,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
 
     const int l31 = lane & 31, h = lane >> 5;
 
-    // ---- phase 1: dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
-    for (int qt = wave; qt < nq; qt += 8) {
+    for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(next_item, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= 2 * nq) break;
+    // ---- dQ item: dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
+    if (item >= nq) {
+        const int qt = item - nq;
         const int qi = qt * 32 + l31;
         bf16x8 qf[4], df[4];
 #pragma unroll
@@ -321,8 +332,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
         }
     }
 
-    // ---- phase 2: dV^T[d][k] = sum_q dO^T[d][q] Pd[q][k] ; dK^T[d][k] = sum_q Q^T[d][q] dS[q][k]
-    for (int kt = wave; kt < nq; kt += 8) {
+    // ---- dK/dV item: dV^T[d][k] = sum_q dO^T[d][q] Pd[q][k] ; dK^T[d][k] = sum_q Q^T[d][q] dS[q][k]
+    else {
+        const int kt = item;
         const int ki = kt * 32 + l31;
         bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                 }
         }
     }
+    }
 }
 
 int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
@@ -405,7 +418,7 @@ int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     return 0;
 }
 int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
-    const int LDS = nt * 32 * 512 + nt * 32 * 16;
+    const int LDS = nt * 32 * 512 + nt * 32 * 16 + 16;
     static int max_set = 65536;
     if (LDS > max_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
