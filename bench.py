@@ -98,6 +98,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropout', action='store_true')
     ap.add_argument('--force-reducer', action='store_true', help='run the RCCL gradient reducer even at world size 1')
+    ap.add_argument('--objective', default='vl', choices=['vl', 'full'],
+                    help="vl = one VL forward_features + backward (headline metric); full = VlmoModule.forward with "
+                         "[mlm, mim, itc, itm] incl. the in-loop dVAE tokenizer (BASELINE.json configs[4])")
+    ap.add_argument('--zero2', action='store_true', help='reduce-scatter gradients (ZeRO-2 style partition, ds_stage/l2.yaml)')
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -119,17 +123,26 @@ def main():
     from exploremultimodal_amd import engine, hip
     from oracle import synth
     hip.lib()
-    model, mc = build_model(args.preset, dev, drop=0.0 if args.no_dropout else 0.1)
+    drop = 0.0 if args.no_dropout else 0.1
+    if args.objective == 'full':
+        from exploremultimodal_amd.build import build_model as build_module
+        cfg = synth.make_config(args.preset, loss_names=['mlm', 'mim', 'itc', 'itm'], drop_rate=drop,
+                                attn_drop_rate=drop, drop_path_rate=drop)
+        torch.manual_seed(0)
+        model, mc = build_module(cfg).to(dev), cfg.model
+    else:
+        model, mc = build_model(args.preset, dev, drop=drop)
     model.train()
     if args.tile is not None:
         engine.DEFAULT_TILE = args.tile
     reducer = None
     if dist is not None:
         from exploremultimodal_amd.dp import GradReducer
-        reducer = GradReducer(model, dist.group.WORLD)
+        reducer = GradReducer(model, dist.group.WORLD, reduce_scatter=args.zero2)
 
     B = args.batch
-    batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=False)
+    batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=args.objective == 'full')
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
     P = synth.num_img_tokens(mc)
     img = batch['image'].to(dev)
     ids, tmask = batch['text_ids'].to(dev), batch['text_mask'].to(dev)
@@ -139,8 +152,12 @@ def main():
     def step():
         for p in model.parameters():
             p.grad = None
-        x, _ = model.forward_features(img=img, txt=ids, img_attn_masks=imask, txt_attn_masks=tmask)
-        loss = (x * R).sum()
+        if args.objective == 'full':
+            ret = model(dict(dbatch))
+            loss = sum(v for k, v in ret.items() if 'task_loss' in k)
+        else:
+            x, _ = model.forward_features(img=img, txt=ids, img_attn_masks=imask, txt_attn_masks=tmask)
+            loss = (x * R).sum()
         if reducer is not None:
             reducer.prepare(loss)
         loss.backward()
@@ -185,6 +202,12 @@ def main():
         pairs = B * world * args.steps / dt
         fl = 3 * fwd_flops_per_pair(mc.embed_dim, mc.depth, mc.fusion_layer, mc.max_text_len, P,
                                     mc.in_chans * mc.patch_size ** 2)
+        if args.objective == 'full':   # 4 VL + 2 V + 1 L backbone passes, 3 of the VL-sized ones on 2B... per pair:
+            d_, L_, F_, T_ = mc.embed_dim, mc.depth, mc.fusion_layer, mc.max_text_len
+            blk = lambda n: 24 * n * d_ * d_ + 4 * n * n * d_
+            v_only = 2 * (P - 1) * mc.in_chans * mc.patch_size ** 2 * d_ + L_ * blk(P)
+            l_only = L_ * blk(T_)
+            fl = 3 * (4 * fl // 3 + 2 * v_only + l_only) + int(52.119e9)      # + dVAE forward per image
         # dominant kernel: per-symbol totals from the event pairs recorded in the timed region
         per = {sym: [sec, flops, n] for sym, (sec, flops, n) in prof.items()}
         dom = max(per.items(), key=lambda kv: kv[1][0]) if per else None
@@ -210,9 +233,11 @@ def main():
             'value': round(pairs, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'VLMo-{args.preset} VL forward_features fwd+bwd, per-GPU batch {B} synthetic '
-                                   f'224x224 image + {mc.max_text_len}-token text pairs, dropout/drop-path '
-                                   f'{0.0 if args.no_dropout else 0.1}',
+            'config': {'workload': (f'VLMo-{args.preset} VL forward_features fwd+bwd' if args.objective == 'vl' else
+                                    f'VLMo-{args.preset} VlmoModule.forward [mlm,mim,itc,itm] + in-loop dVAE, fwd+bwd'
+                                    + (', ZeRO-2 grad partition' if args.zero2 else '')) +
+                                   f', per-GPU batch {B} synthetic 224x224 image + {mc.max_text_len}-token text '
+                                   f'pairs, dropout/drop-path {0.0 if args.no_dropout else 0.1}',
                        'global_batch': B * world, 'seq_len': mc.max_text_len + P,
                        'parallelism': f'dp{world}'},
             'step_tflops': round(fl * B * world * args.steps / dt / 1e12, 1),

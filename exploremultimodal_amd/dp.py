@@ -153,7 +153,12 @@ class GradReducer:
         self._armed = True
 
     # ---- engine sink protocol (called from engine.BlockFn) -------------------------------------------
-    def expect(self, key):
+    @staticmethod
+    def _key(group):
+        return tuple(id(p) for p in group)
+
+    def expect(self, group):
+        key = self._key(group)
         sb = self.sinks.get(key)
         if sb is not None:
             sb.expected += 1
@@ -161,7 +166,8 @@ class GradReducer:
             self._pending_expect = getattr(self, '_pending_expect', {})
             self._pending_expect[key] = self._pending_expect.get(key, 0) + 1
 
-    def acquire(self, key, numel, device):
+    def acquire(self, group, numel, device):
+        key = self._key(group)
         sb = self.sinks.get(key)
         if sb is None:
             sb = _SinkBucket(numel, device, self.comm_dtype, self.world)
@@ -178,8 +184,8 @@ class GradReducer:
             sb.fresh = False
         return sb.flat[:numel]
 
-    def release(self, key):
-        sb = self.sinks[key]
+    def release(self, group):
+        sb = self.sinks[self._key(group)]
         sb.expected -= 1
         if sb.expected <= 0:
             self._launch_sink(sb)

@@ -253,8 +253,10 @@ class BlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, *params)
             ctx.sink = GRAD_SINK
             if ctx.sink is not None:
-                ctx.sink_key = tuple(id(p) for p in params)
-                ctx.sink.expect(ctx.sink_key)
+                # one bucket for the block's shared parameters, one per expert used by this call
+                ctx.sink_groups = [tuple(params[:11])] + [tuple(e) for e in experts]
+                for g_ in ctx.sink_groups:
+                    ctx.sink.expect(g_)
         return x2
 
     @staticmethod
@@ -267,29 +269,33 @@ class BlockFn(torch.autograd.Function):
         f32 = torch.float32
         dx2 = dx2.contiguous()
         # every parameter gradient of this block lives in ONE zero-filled flat buffer (one memset)
-        total = 6 * d + 3 * d * d + d * d + d + 3 * d + nexp * (2 * hid * d + hid + d)
         sink = ctx.sink
-        if sink is not None:    # data-parallel run: accumulate into the reducer's persistent flat bucket
-            flat = sink.acquire(ctx.sink_key, total, dev)
-        else:
-            flat = torch.zeros(total, dtype=f32, device=dev)
-        off = [0]
+        shared_n = 6 * d + 3 * d * d + d * d + d + 3 * d
+        exp_n = 2 * hid * d + hid + d
+        if sink is not None:    # data-parallel run: accumulate straight into the reducer's persistent flat buckets
+            flats = [sink.acquire(ctx.sink_groups[0], shared_n, dev)] + \
+                    [sink.acquire(g_, exp_n, dev) for g_ in ctx.sink_groups[1:]]
+        else:                   # ONE zero-filled flat buffer (one memset) carved into all gradients of the block
+            whole = torch.zeros(shared_n + nexp * exp_n, dtype=f32, device=dev)
+            flats = [whole[:shared_n]] + [whole[shared_n + i * exp_n: shared_n + (i + 1) * exp_n] for i in range(nexp)]
 
-        def z(*shape):
-            n = 1
-            for s_ in shape:
-                n *= s_
-            t = flat[off[0]:off[0] + n].view(*shape)
-            off[0] += n
-            return t
+        def carve(flat, shapes):
+            out, off = [], 0
+            for shp in shapes:
+                n = 1
+                for s_ in shp:
+                    n *= s_
+                out.append(flat[off:off + n].view(*shp))
+                off += n
+            return out
 
-        dg1, dg2, dn1w, dn1b, dn2w, dn2b = z(d), z(d), z(d), z(d), z(d), z(d)
-        dqkv_w, dproj_w, dproj_b, dqkv_b = z(3 * d, d), z(d, d), z(d), z(3 * d)
+        (dg1, dg2, dn1w, dn1b, dn2w, dn2b, dqkv_w, dproj_w, dproj_b, dqkv_b) = carve(
+            flats[0], [(d,)] * 6 + [(3 * d, d), (d, d), (d,), (3 * d,)])
         D.dg1, D.dg2, D.dn1w, D.dn1b, D.dn2w, D.dn2b = (t.data_ptr() for t in (dg1, dg2, dn1w, dn1b, dn2w, dn2b))
         D.dqkv_w, D.dproj_w, D.dproj_b, D.dqkv_b = (t.data_ptr() for t in (dqkv_w, dproj_w, dproj_b, dqkv_b))
         dexp = []
         for i in range(nexp):
-            dw1, db1, dw2, db2 = z(hid, d), z(hid), z(d, hid), z(d)
+            dw1, db1, dw2, db2 = carve(flats[1 + i], [(hid, d), (hid,), (d, hid), (d,)])
             D.dw1[i], D.db1[i], D.dw2[i], D.db2[i] = dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
             dexp += [dw1, db1, dw2, db2]
         # temporaries: dz2 | du(4) | dy2(=dctx) | dz1 | dqkv(3) | dy1  bf16 ; dx1, dx0 fp32
@@ -327,7 +333,8 @@ class BlockFn(torch.autograd.Function):
                     elif p_.grad.data_ptr() != g_.data_ptr():
                         raise RuntimeError('a parameter of a data-parallel block already holds a foreign .grad; '
                                            'use zero_grad(set_to_none=True)')
-            sink.release(ctx.sink_key)
+            for g_ in ctx.sink_groups:
+                sink.release(g_)
             return (dx0, None) + (None,) * len(grads)
         return (dx0, None, *grads)
 

@@ -88,10 +88,6 @@ _SIGS = {
 }
 
 _lib = None
-# bench.py sets this to a dict to collect (start, end) event pairs around GEMM launches,
-# keyed by (kernel symbol, algorithmic flops of the launch)
-PROFILE = None
-
 
 def lib():
     """Load (once) and return the C-ABI library; raise loudly if it is missing."""
@@ -171,16 +167,9 @@ def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=
                  ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else
                                               (aux.stride(0) if aux is not None else 0)),
                  int(relu), drop[0], drop[1], beta, seed & 0xFFFFFFFFFFFFFFFF)
-    ev = None
-    if PROFILE is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     rc = lib().vlmo_gemm_nt(epi, _dt(A), tile, _p(A), lda if lda is not None else A.stride(0),
                             _p(B), ldb if ldb is not None else B.stride(0), M, N, K,
                             ctypes.byref(e), _stream())
-    if ev is not None:
-        ev[1].record()
-        PROFILE.setdefault((f'gemm_nt_kernel<epi={epi},tile={tile}>', 2 * M * N * K), []).append(ev)
     _check(rc, 'vlmo_gemm_nt')
 
 
@@ -198,17 +187,10 @@ def tn_workspace(device, nbytes):
 
 
 def gemm_tn(A, B, C, M, N1, N2, alpha=1.0, splits=0, slab=True):
-    ev = None
-    if PROFILE is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     ws = tn_workspace(A.device, max(splits, 16) * N1 * N2 * 4 if splits > 0 else
                       lib().vlmo_gemm_tn_ws_bytes(M, N1, N2)) if slab else None
     rc = lib().vlmo_gemm_tn(_dt(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(C), C.stride(0),
                             M, N1, N2, alpha, splits, _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
-    if ev is not None:
-        ev[1].record()
-        PROFILE.setdefault(('gemm_tn_kernel', 2 * M * N1 * N2), []).append(ev)
     _check(rc, 'vlmo_gemm_tn')
 
 
@@ -316,15 +298,8 @@ def conv2d_nhwc(epi, x, B, H, W, Cin, kw, w, Cout, out, *, out2=None, bias=None,
     e = Epilogue(_p(out), _p(out2), _p(bias), None, _p(resid), None, None, None,
                  ldo if ldo is not None else out.stride(0), out2.stride(0) if out2 is not None else 0,
                  int(relu), 0, 1.0, beta, 0)
-    ev = None
-    if PROFILE is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     rc = lib().vlmo_conv2d_nhwc(epi, _dt(x), _p(x), B, H, W, Cin, kw, _p(w), Cout, _p(zero_page(x.device)),
                                 ctypes.byref(e), _stream())
-    if ev is not None:
-        ev[1].record()
-        PROFILE.setdefault((f'conv_nt_kernel<epi={epi}>', 2 * B * H * W * Cout * kw * kw * Cin), []).append(ev)
     _check(rc, 'vlmo_conv2d_nhwc')
 
 
