@@ -55,8 +55,11 @@ __device__ __forceinline__ void stage_image(const bf16* base, int ld, int col0, 
     }
 }
 
+__device__ __forceinline__ uint64_t att_drop_group(int bh, int q, int key) {
+    return ((uint64_t)bh * 4096 + q) * 1024 + (key >> 2);
+}
 __device__ __forceinline__ uint64_t att_drop_bits(uint64_t seed, int bh, int q, int key) {
-    return drop_bits4(seed, ((uint64_t)bh * 4096 + q) * 1024 + (key >> 2));
+    return drop_bits4(seed, att_drop_group(bh, q, key));
 }
 
 // B/A operand by row read: rows row_base + (lane&31), features 16*ks + 8*(lane>>5) ..+7
@@ -364,8 +367,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                         const float p = exp2f(S[i] * a.scale_log2e + kb - lq[e]);
                         float dp = dP[i], pd = p;
                         if (a.drop_thresh) {
-                            const uint64_t bits = att_drop_bits(a.seed, bh, q0 + e, ki);
-                            const bool keep = drop_keep(bits, ki & 3, a.drop_thresh);
+                            const bool keep = drop_keep1(a.seed, att_drop_group(bh, q0 + e, ki), ki & 3, a.drop_thresh);
                             dp = keep ? dp * a.inv_keep : 0.f;
                             pd = keep ? p * a.inv_keep : 0.f;
                         }

@@ -84,19 +84,33 @@ __device__ __forceinline__ f16x4 lds_tr4<f16>(const void* p) {
     return __builtin_bit_cast(f16x4, r);
 }
 
-// ---- counter-based RNG for dropout: one 64-bit hash -> four 16-bit lanes ---
-// keep(e) <=> u16(e) >= thresh, thresh = round(p * 65536).  Forward and
-// backward regenerate the same mask from (seed, element-group index).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// ---- counter-based RNG for dropout -----------------------------------------------------------
+// keep(e) <=> u16(e) >= thresh, thresh = round(p * 65536).  Forward and backward regenerate the
+// same mask from (seed, element-group index): group g covers 4 consecutive elements, elements
+// 2h and 2h+1 of it take the low / high 16 bits of hash32(seed, 2g + h).  One 32-bit hash
+// (2 multiplies, 3 xor-shifts) serves two elements; a kernel whose lanes hold single elements of a
+// group (attention backward, keys on lanes) evaluates only the half it needs.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_half(uint64_t seed, uint64_t group_idx, int half) {
+    const uint32_t i = (uint32_t)(group_idx * 2 + half);
+    return hash32((i ^ (uint32_t)seed) * 0x9E3779B9u + (uint32_t)(seed >> 32));
 }
 __device__ __forceinline__ uint64_t drop_bits4(uint64_t seed, uint64_t group_idx) {
-    return mix64(seed + group_idx * 0x9E3779B97F4A7C15ull);
+    return (uint64_t)drop_half(seed, group_idx, 0) | ((uint64_t)drop_half(seed, group_idx, 1) << 32);
 }
 __device__ __forceinline__ bool drop_keep(uint64_t bits, int j, uint32_t thresh) {
     return ((uint32_t)(bits >> (16 * j)) & 0xFFFFu) >= thresh;
+}
+// element j (0..3) of a group without computing the other half
+__device__ __forceinline__ bool drop_keep1(uint64_t seed, uint64_t group_idx, int j, uint32_t thresh) {
+    return ((drop_half(seed, group_idx, j >> 1) >> (16 * (j & 1))) & 0xFFFFu) >= thresh;
 }
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16/f16 output

@@ -159,6 +159,7 @@ class GradReducer:
 
     def expect(self, group):
         key = self._key(group)
+        self._sink_params.update(key)      # known before prepare(loss): these never take the hook path
         sb = self.sinks.get(key)
         if sb is not None:
             sb.expected += 1
