@@ -198,7 +198,11 @@ class GradReducer:
             sb.flat.mul_(1.0 / self.world)
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.comm_stream):
+            ctxm = torch.cuda.stream(self.comm_stream)
+        else:
+            from contextlib import nullcontext
+            ctxm = nullcontext()
+        with ctxm:
             if self.reduce_scatter:
                 sb.shard = torch.empty(sb.padded // self.world, dtype=sb.comm.dtype, device=self.device)
                 sb.work = dist.reduce_scatter_tensor(sb.shard, sb.comm, group=self.pg, async_op=True)

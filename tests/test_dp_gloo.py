@@ -91,6 +91,58 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
+def _sink_worker(rank, world, port, q):
+    """The engine-sink protocol (expect / acquire / release / finish) that BlockFn drives, on CPU tensors:
+    two 'passes' accumulate into one bucket before it is reduced; a second step re-zeroes it."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from exploremultimodal_amd.dp import GradReducer
+        model = Tiny()
+        red = GradReducer(model, engine_sink=False)
+        group = tuple(model.blocks[0]['a'].parameters())
+        other = tuple(model.blocks[1]['a'].parameters())
+        n = sum(p.numel() for p in group)
+        for step in range(2):
+            red.expect(group)
+            red.expect(group)          # the block is used by two passes of this step
+            red.expect(other)
+            red._armed = True
+            for k in range(2):
+                flat = red.acquire(group, n, torch.device('cpu'))
+                flat += (rank + 1) * (k + 1) * (step + 1)
+                red.release(group)
+            f2 = red.acquire(other, n, torch.device('cpu'))
+            f2 += 10.0 * (rank + 1)
+            red.release(other)
+            red.finish()
+            want = sum((r + 1) * 3 * (step + 1) for r in range(world)) / world
+            got = red.sinks[red._key(group)].flat[:n]
+            assert torch.allclose(got, torch.full_like(got, want)), (step, got[:3], want)
+            got2 = red.sinks[red._key(other)].flat[:n]
+            assert torch.allclose(got2, torch.full_like(got2, 10.0 * sum(r + 1 for r in range(world)) / world))
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_sink_protocol_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
+
+
 @pytest.mark.parametrize('mode', ['allreduce', 'rs'])
 def test_grad_reducer_world2_gloo(mode):
     ctx = mp.get_context('spawn')
