@@ -366,55 +366,73 @@ struct GemmTN {
 // dual-use 256-byte-row image: chunk swizzle serving the transposed reads
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
+// Output tile BM x BN (multiples of 128) per workgroup of WM x WN waves; each operand's K-tile (64 token rows)
+// is staged as BM/128 resp. BN/128 side-by-side sub-images of [64 rows][128 columns] in the dual-use swizzle.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p) {
     typedef typename Elem<T>::v8 v8;
     typedef typename Elem<T>::v4 v4;
-    constexpr int TILE_BYTES = 64 * 256, STAGE = 2 * TILE_BYTES;
+    constexpr int NW = WM * WN;
+    constexpr int SUB = 64 * 256;                       // one sub-image
+    constexpr int NSA = BM / 128, NSB = BN / 128;
+    constexpr int A_BYTES = NSA * SUB, STAGE = (NSA + NSB) * SUB;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int IA = NSA * 16 / NW, IB = NSB * 16 / NW;   // LDS-DMA instructions per wave per K-tile
+    static_assert((NSA * 16) % NW == 0 && (NSB * 16) % NW == 0, "tile/wave mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N2 + 127) / 128;
-    const int n1_0 = (blockIdx.x / tiles_n) * 128, n2_0 = (blockIdx.x % tiles_n) * 128;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N2 + BN - 1) / BN;
+    const int n1_0 = (blockIdx.x / tiles_n) * BM, n2_0 = (blockIdx.x % tiles_n) * BN;
     const int nk_total = (p.M + 63) >> 6;
     const int kt0 = blockIdx.y * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
     if (kt0 >= kt1) return;
 
-    // staging: one wave-instruction = 4 rows x 256 B; 16 instructions per operand tile
-    int a_off[4], b_off[4], srow[4];
+    // staging: one wave-instruction = 4 rows x 256 B of one sub-image; 16 instructions per sub-image
+    int a_off[IA], b_off[IB], a_row[IA], b_row[IB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 4 + wave) * 4 + (lane >> 4);
+    for (int i = 0; i < IA; ++i) {
+        const int ii = i * NW + wave, sub = ii >> 4, row = (ii & 15) * 4 + (lane >> 4);
         const int ch = (lane & 15) ^ tn_swz(row);
-        srow[i] = row;
-        a_off[i] = min(n1_0 + ch * 8, p.N1 - 8);
-        b_off[i] = min(n2_0 + ch * 8, p.N2 - 8);
+        a_row[i] = row;
+        a_off[i] = min(n1_0 + sub * 128 + ch * 8, p.N1 - 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int ii = i * NW + wave, sub = ii >> 4, row = (ii & 15) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ tn_swz(row);
+        b_row[i] = row;
+        b_off[i] = min(n2_0 + sub * 128 + ch * 8, p.N2 - 8);
     }
     auto stage = [&](int buf, int kt) {
         char* s = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr = min(kt * 64 + srow[i], p.M - 1);
-            glds16((const T*)p.A + (size_t)gr * p.lda + a_off[i], s + (i * 4 + wave) * 1024);
-            glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + TILE_BYTES + (i * 4 + wave) * 1024);
+        for (int i = 0; i < IA; ++i) {
+            const int gr = min(kt * 64 + a_row[i], p.M - 1);
+            glds16((const T*)p.A + (size_t)gr * p.lda + a_off[i], s + (i * NW + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int gr = min(kt * 64 + b_row[i], p.M - 1);
+            glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
     // transposed-read addressing (ds_read_b64_tr_b16): lane 4q+p of a 16-lane
     // group supplies row q, columns 4p..4p+3 of a 4x16 block
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = lane >> 5;
-    const int ncol_a = wm * 64 + 16 * (g & 1) + 4 * pp;   // + tile*32
-    const int ncol_b = wn * 64 + 16 * (g & 1) + 4 * pp;
+    const int ncol_a = wm * (BM / WM) + 16 * (g & 1) + 4 * pp;   // + tile*32
+    const int ncol_b = wn * (BN / WN) + 16 * (g & 1) + 4 * pp;
 
     stage(0, kt0);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -425,21 +443,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         const bool tail = (kt * 64 + 64 > p.M);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            v8 af[2], bf[2];
+            v8 af[TM], bf[TN];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int m = 16 * ks + 8 * h + 4 * half + q;
                 const int sw = tn_swz(m);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int na = ncol_a + t * 32, nb = ncol_b + t * 32;
-                    const v4 va = lds_tr4<T>(s + m * 256 + (((na >> 3) ^ sw) << 4) + (na & 7) * 2);
-                    const v4 vb = lds_tr4<T>(s + TILE_BYTES + m * 256 + (((nb >> 3) ^ sw) << 4) + (nb & 7) * 2);
+                for (int t = 0; t < TM; ++t) {
+                    const int na = ncol_a + t * 32;
+                    const v4 va = lds_tr4<T>(s + (na >> 7) * SUB + m * 256 + ((((na & 127) >> 3) ^ sw) << 4) + (na & 7) * 2);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        af[t][4 * half + e] = va[e];
-                        bf[t][4 * half + e] = vb[e];
-                    }
+                    for (int e = 0; e < 4; ++e) af[t][4 * half + e] = va[e];
+                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const int nb = ncol_b + t * 32;
+                    const v4 vb = lds_tr4<T>(s + A_BYTES + (nb >> 7) * SUB + m * 256 + ((((nb & 127) >> 3) ^ sw) << 4) + (nb & 7) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[t][4 * half + e] = vb[e];
                 }
             }
             if (tail) {
@@ -448,27 +469,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
                 for (int e = 0; e < 8; ++e) {
                     const bool ok = (kt * 64 + 16 * ks + 8 * h + e) < p.M;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < TM; ++t)
                         if (!ok) af[t][e] = (T)0.f;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
         }
     }
     // epilogue: lane = output column, register = output row: each half-wave
-    // adds 128 contiguous bytes (the full-rate atomic shape)
+    // writes / adds 128 contiguous bytes
     const int l31 = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gn = n2_0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n2_0 + wn * (BN / WN) + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gm = n1_0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gm = n1_0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (gm < p.N1 && gn < p.N2) {
                     if (p.slab)
                         p.slab[((size_t)blockIdx.y * p.N1 + gm) * p.N2 + gn] = acc[i][j][r];
@@ -640,17 +661,45 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     if (tile == 1) return launch_nt<bf16, 256, 128, 4, 2>(epi, p, stream);
     if (tile == 2) return launch_nt<bf16, 128, 128, 2, 2, false, 32, 4>(epi, p, stream);
     if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4>(epi, p, stream);
+    if (tile == 4) return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
 }
 
-extern "C" int64_t vlmo_gemm_tn_ws_bytes(int M, int N1, int N2) {
-    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
-    int splits = 512 / tiles;
-    if (splits < 4) splits = 1024 / tiles;
-    if (splits < 1) splits = 1;
+namespace {
+// tile / split plan of the weight-gradient GEMM: 256x256 tiles (half the staged bytes per flop, one
+// workgroup per CU) when they fill the chip in ONE dispatch round with <= 16 splits, else 128x128 tiles
+// (two workgroups per CU) with the fewest splits that fill whole rounds of 512 workgroup slots.
+struct TnPlan {
+    int big, tiles, splits, per;
+};
+TnPlan tn_plan(int M, int N1, int N2, int splits_req, int force_tile) {
     const int nk = (M + 63) / 64;
+    TnPlan pl{};
+    const int t256 = ((N1 + 255) / 256) * ((N2 + 255) / 256);
+    const int t128 = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    const bool big_ok = N1 >= 256 && N2 >= 256 && nk >= 16 && t256 <= 256;
+    pl.big = force_tile == 256 ? 1 : (force_tile == 128 ? 0 : (big_ok && (256 / t256) <= 16 && (256 / t256) >= 1 && nk / (256 / t256) >= 8));
+    pl.tiles = pl.big ? t256 : t128;
+    int splits = splits_req;
+    if (splits <= 0) {
+        if (pl.big) {
+            splits = 256 / pl.tiles;
+        } else {
+            splits = 512 / pl.tiles;
+            if (splits < 4) splits = 1024 / pl.tiles;
+        }
+        if (splits < 1) splits = 1;
+    }
     if (splits > nk) splits = nk;
-    return (int64_t)splits * N1 * N2 * 4;
+    pl.per = (nk + splits - 1) / splits;
+    pl.splits = (nk + pl.per - 1) / pl.per;
+    return pl;
+}
+}  // namespace
+
+extern "C" int64_t vlmo_gemm_tn_ws_bytes(int M, int N1, int N2) {
+    const TnPlan a = tn_plan(M, N1, N2, 0, 0);
+    return (int64_t)a.splits * N1 * N2 * 4;
 }
 
 extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
@@ -661,36 +710,42 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     VLMO_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "vlmo_gemm_tn: N1,N2,lda,ldb must be multiples of 8");
     VLMO_CHECK_ARG(lda >= N1 && ldb >= N2 && ldc >= N2, "vlmo_gemm_tn: leading dimension too small");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn: dtype must be bf16 or f16");
-    const int nk = (M + 63) / 64;
-    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
-    if (splits <= 0) {
-        // every split adds N1*N2*4 bytes of fp32 atomics (~1.3 TB/s chip-wide): use the fewest splits that
-        // still give about two workgroups per CU
-        // still fill whole dispatch rounds (512 workgroup slots = 2 per CU): measured on MI355X, a last
-        // round that is mostly empty costs more than the extra atomics of a fuller one
-        splits = 512 / tiles;
-        if (splits < 4) splits = 1024 / tiles;
-        if (splits < 1) splits = 1;
+    int force = 0;
+    if (splits >= 1000) {      // test hook: 1000 + s forces 128x128 tiles, 2000 + s forces 256x256
+        force = splits >= 2000 ? 256 : 128;
+        splits %= 1000;
     }
-    if (splits > nk) splits = nk;
-    const int per = (nk + splits - 1) / splits;
-    splits = (nk + per - 1) / per;
+    const TnPlan pl = tn_plan(M, N1, N2, splits, force);
     // partial products go to a caller-owned slab (plain stores, then one reduction pass) when the workspace is
     // big enough and there is more than one split; else straight into C with fp32 atomics.  Measured on MI355X:
     // 7 splits of a 3072x768 gradient as atomics cost ~30 us of a 135 us launch (memory-side atomic rate).
-    const bool use_slab = ws && splits > 1 && N2 % 4 == 0 && ldc % 4 == 0 && ws_bytes >= (int64_t)splits * N1 * N2 * 4;
-    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, per, alpha, use_slab ? ws : nullptr};
-    dim3 grid(tiles, splits), block(256);
-    ProfScope prof(64, 2.0 * M * N1 * N2, stream);
-    if (dtype == VLMO_F16)
-        hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, 65536, stream, p);
-    else
-        hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, 65536, stream, p);
+    const bool use_slab = ws && pl.splits > 1 && N2 % 4 == 0 && ldc % 4 == 0 && ws_bytes >= (int64_t)pl.splits * N1 * N2 * 4;
+    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, pl.per, alpha, use_slab ? ws : nullptr};
+    dim3 grid(pl.tiles, pl.splits);
+    ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
+    if (pl.big) {
+        constexpr int LDS = 2 * 4 * 64 * 256;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16, 256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr = true;
+        }
+        if (dtype == VLMO_F16)
+            hipLaunchKernelGGL((gemm_tn_kernel<f16, 256, 256, 2, 4>), grid, dim3(512), LDS, stream, p);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4>), grid, dim3(512), LDS, stream, p);
+    } else {
+        if (dtype == VLMO_F16)
+            hipLaunchKernelGGL((gemm_tn_kernel<f16, 128, 128, 2, 2>), grid, dim3(256), 65536, stream, p);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 128, 128, 2, 2>), grid, dim3(256), 65536, stream, p);
+    }
     VLMO_CHECK_LAUNCH("vlmo_gemm_tn");
     if (use_slab) {
         const long total = (long)N1 * (N2 / 4);
         const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(rg), dim3(256), 0, stream, ws, splits, N1, N2, C, ldc, alpha);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(rg), dim3(256), 0, stream, ws, pl.splits, N1, N2, C, ldc, alpha);
         VLMO_CHECK_LAUNCH("vlmo_gemm_tn(reduce)");
     }
     return 0;

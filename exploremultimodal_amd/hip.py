@@ -187,7 +187,7 @@ def tn_workspace(device, nbytes):
 
 
 def gemm_tn(A, B, C, M, N1, N2, alpha=1.0, splits=0, slab=True):
-    ws = tn_workspace(A.device, max(splits, 16) * N1 * N2 * 4 if splits > 0 else
+    ws = tn_workspace(A.device, max(splits % 1000, 16) * N1 * N2 * 4 if splits > 0 else
                       lib().vlmo_gemm_tn_ws_bytes(M, N1, N2)) if slab else None
     rc = lib().vlmo_gemm_tn(_dt(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(C), C.stride(0),
                             M, N1, N2, alpha, splits, _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
@@ -340,8 +340,8 @@ def profile_stop():
     out = {}
     for t in range(n):
         if ln[t]:
-            if t == 64:
-                name = 'gemm_tn_kernel'
+            if t in (64, 72):
+                name = 'gemm_tn_kernel<%s>' % ('256x256' if t == 72 else '128x128')
             elif t >= 32:
                 name = f'conv_nt_kernel<{names.get(t - 32, t - 32)}>'
             else:

@@ -136,6 +136,22 @@ def test_gemm_tn_wgrad(M, N1, N2):
     _close(C, 0 * ref, 2e-3, 6e-3 * math.sqrt(M), 'wgrad atomics')
 
 
+@pytest.mark.parametrize('force', [1001, 2001, 2003])
+def test_gemm_tn_tile_variants_exact(force):
+    """both tile shapes of the wgrad kernel (128x128 and 256x256 sub-image tiles), exact integer data,
+    ragged M / N1 / N2 (splits >= 1000 is the test hook that forces a tile shape)."""
+    M, N1, N2 = 700, 384, 520
+    g = torch.Generator().manual_seed(force)
+    A = torch.randint(-3, 4, (M, N1), generator=g).float()
+    B = torch.randint(-2, 3, (M, N2), generator=g).float()
+    A[:, 0] += torch.arange(M).float() % 3
+    C = torch.zeros(N1, N2, device=DEV)
+    hip.gemm_tn(A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), C, M, N1, N2, splits=force)
+    assert torch.equal(C.cpu(), A.t() @ B)
+    hip.gemm_tn(A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), C, M, N1, N2, splits=force, slab=False)
+    assert torch.equal(C.cpu(), 2 * (A.t() @ B))
+
+
 def test_gemm_tn_exact_integers():
     M, N1, N2 = 200, 128, 256
     g = torch.Generator().manual_seed(5)
