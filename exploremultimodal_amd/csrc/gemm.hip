@@ -661,7 +661,6 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     if (tile == 1) return launch_nt<bf16, 256, 128, 4, 2>(epi, p, stream);
     if (tile == 2) return launch_nt<bf16, 128, 128, 2, 2, false, 32, 4>(epi, p, stream);
     if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4>(epi, p, stream);
-    if (tile == 4) return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
 }
 
