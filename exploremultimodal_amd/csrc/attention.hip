@@ -156,14 +156,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const bool dead = (m_new == -INFINITY);            // every key so far is masked
-            const float alpha = dead ? 1.f : exp2f(m_run - m_new);
+            const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
             float lsum = 0.f;
 #pragma unroll
             for (int c = 0; c < ATT_CK; ++c) {
                 if (c0 + c < nq) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const float p = dead ? 0.f : exp2f(S[c][i] - m_new);
+                        const float p = dead ? 0.f : __builtin_amdgcn_exp2f(S[c][i] - m_new);
                         S[c][i] = p;
                         lsum += p;
                     }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g4 + e;
-                        const float p = exp2f(S[i] * a.scale_log2e + kb[e] - lq);
+                        const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + kb[e] - lq);
                         float dp = dP[i];
                         if (a.drop_thresh) dp = drop_keep(bits, e, a.drop_thresh) ? dp * a.inv_keep : 0.f;
                         S[i] = p * (dp - dl) * a.scale;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g4 + e;
-                        const float p = exp2f(S[i] * a.scale_log2e + kb - lq[e]);
+                        const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + kb - lq[e]);
                         float dp = dP[i], pd = p;
                         if (a.drop_thresh) {
                             const bool keep = drop_keep1(a.seed, att_drop_group(bh, q0 + e, ki), ki & 3, a.drop_thresh);

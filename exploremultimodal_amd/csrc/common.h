@@ -118,21 +118,25 @@ __device__ __forceinline__ bool drop_keep1(uint64_t seed, uint64_t group_idx, in
 // instructions -- the GELU epilogues run once per GEMM output element.
 // e = exp(-x^2/2) is shared between the erf tail and the Gaussian pdf.
 __device__ __forceinline__ float norm_cdf_from(float x, float e) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float tail = 0.5f * poly * t * e;          // 0.5 * erfc(|x|/sqrt2)
+    // v_rcp_f32 (1 ulp) rather than an IEEE divide: the latter expands to ~11 VALU ops
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    const float tail = poly * t * e;                 // 0.5 * erfc(|x|/sqrt2)
     return x >= 0.f ? 1.0f - tail : tail;
 }
+// exp(-x^2/2) as one mul + one raw v_exp_f32 (results below 2^-126 flush to 0)
+__device__ __forceinline__ float gauss_from(float x) {
+    return __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float e = __expf(-0.5f * x * x);
+    const float e = gauss_from(x);
     return x * norm_cdf_from(x, e);
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float e = __expf(-0.5f * x * x);
+    const float e = gauss_from(x);
     return norm_cdf_from(x, e) + x * 0.39894228040143268f * e;
 }
 

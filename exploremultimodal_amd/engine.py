@@ -17,7 +17,9 @@ from . import hip
 
 LN_EPS = 1e-12          # vlmo_module.py:21-23
 GRAD_SINK = None         # set by dp.GradReducer: block gradients are accumulated straight into its flat buckets
-OVERLAP_WGRAD = True     # weight-gradient GEMMs + bias column sums on a side stream beside the dgrad chain
+import os as _os
+OVERLAP_WGRAD = _os.environ.get('VLMO_OVERLAP_WGRAD', '1') != '0'   # weight-gradient GEMMs + bias column sums on a side stream
+SIDE_PRIORITY = int(_os.environ.get('VLMO_SIDE_PRIORITY', '0'))
 DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
 
@@ -152,7 +154,7 @@ _SIDE = {}
 def _side_stream(dev):
     s = _SIDE.get(dev)
     if s is None:
-        s = torch.cuda.Stream(device=dev)
+        s = torch.cuda.Stream(device=dev, priority=SIDE_PRIORITY)
         _SIDE[dev] = s
     return s
 
