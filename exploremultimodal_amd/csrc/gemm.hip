@@ -36,6 +36,14 @@ struct GemmNT {
     int group_m;     // L2 tile swizzle: row-tiles per group
 };
 
+// element address split into a wave-uniform 64-bit part and a per-lane 32-bit part
+struct RowAddr {
+    size_t base;
+    uint32_t off;
+    template <typename U> __device__ __forceinline__ U* at(const void* p) const {
+        return (U*)((char*)((U*)p + base) + off * (uint32_t)sizeof(U));
+    }
+};
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, float a, float b, float c, float d) {
     bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
@@ -60,22 +68,27 @@ template <> __device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
 // row segment and `rs` = drop-path scale: loaded for a whole pass BEFORE any math so the ~1-2 us
 // global latencies overlap instead of serialising load -> math -> store per row group).
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4 v, f32x4 bias4, f32x4 gamma4,
-                                          f32x4 ext, float rs) {
+__device__ __forceinline__ void epilogue4(const GemmNT& p, int gmb, int row, int gn, f32x4 v, f32x4 bias4,
+                                          f32x4 gamma4, f32x4 ext, float rs) {
     const VlmoEpilogue& e = p.e;
     v += bias4;
-    const size_t o = (size_t)gm * e.ldo + gn;
+    // wave-uniform 64-bit row base (scalar unit) + 32-bit in-tile offset: a per-lane 64-bit
+    // multiply-add per store costs 4x a plain VALU op
+    // (global_* saddr form: SGPR base + zero-extended 32-bit VGPR byte offset)
+    const int gm = gmb + row;
+    const RowAddr o{(size_t)gmb * e.ldo, (uint32_t)(row * e.ldo + gn)};
+    const RowAddr o2{(size_t)gmb * e.ld2, (uint32_t)(row * e.ld2 + gn)};
     if constexpr (EPI == EPI_BIAS) {
         if (e.relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_F32) {
         if (e.beta != 0.f) v += e.beta * ext;
-        *(f32x4*)((float*)e.out + o) = v;
+        *(f32x4*)o.at<float>(e.out) = v;
     } else if constexpr (EPI == EPI_BIAS_GELU) {
-        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);   // u (pre-activation)
+        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);   // u (pre-activation)
         f32x4 h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = gelu_erf(v[j]);
@@ -84,19 +97,19 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4
 #pragma unroll
             for (int j = 0; j < 4; ++j) h[j] = drop_keep(bits, j, e.drop_thresh) ? h[j] * e.inv_keep : 0.f;
         }
-        store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, h[0], h[1], h[2], h[3]);
+        store4<T>(o2.at<T>(e.out2), h[0], h[1], h[2], h[3]);
     } else if constexpr (EPI == EPI_RESID) {
         if (e.drop_thresh) {
             const uint64_t bits = drop_bits4(e.seed, ((uint64_t)gm * p.N + gn) >> 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
         }
-        if (e.out2) store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, v[0], v[1], v[2], v[3]);
-        *(f32x4*)((float*)e.out + o) = ext + gamma4 * v * rs;
+        if (e.out2) store4<T>(o2.at<T>(e.out2), v[0], v[1], v[2], v[3]);
+        *(f32x4*)o.at<float>(e.out) = ext + gamma4 * v * rs;
     } else if constexpr (EPI == EPI_DUAL) {
         // dVAE EncoderBlock tail (dall_e/encoder.py:45-46): out = id + post_gain * res ; out2 = relu(out)
         v = v * e.beta + ext;
-        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
         if (e.out2)
             store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f),
                       fmaxf(v[3], 0.f));
@@ -108,23 +121,25 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gm, int gn, f32x4
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
         }
-        store4<T>((T*)e.out + o, v[0], v[1], v[2], v[3]);
+        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     }
 }
 
 // the row segment an epilogue needs from global memory besides the accumulators (clamped row: always valid)
 template <typename T, int EPI>
-__device__ __forceinline__ f32x4 epilogue_ext(const GemmNT& p, int gmc, int gnc) {
+__device__ __forceinline__ f32x4 epilogue_ext(const GemmNT& p, int gmb, int rowc, int gnc) {
     const VlmoEpilogue& e = p.e;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const RowAddr o{(size_t)gmb * e.ldo, (uint32_t)(rowc * e.ldo + gnc)};
+    const RowAddr o2{(size_t)gmb * e.ld2, (uint32_t)(rowc * e.ld2 + gnc)};
     if constexpr (EPI == EPI_RESID) {
-        return *(const f32x4*)(e.resid + (size_t)gmc * e.ldo + gnc);
+        return *(const f32x4*)o.at<float>(e.resid);
     } else if constexpr (EPI == EPI_DGELU) {
-        return load4<T>((const T*)e.aux + (size_t)gmc * e.ld2 + gnc);
+        return load4<T>(o2.at<T>(e.aux));
     } else if constexpr (EPI == EPI_DUAL) {
-        return e.resid ? load4<T>((const T*)e.resid + (size_t)gmc * e.ldo + gnc) : z;
+        return e.resid ? load4<T>(o.at<T>(e.resid)) : z;
     } else if constexpr (EPI == EPI_F32) {
-        return e.beta != 0.f ? *(const f32x4*)((const float*)e.out + (size_t)gmc * e.ldo + gnc) : z;
+        return e.beta != 0.f ? *(const f32x4*)o.at<float>(e.out) : z;
     } else {
         return z;
     }
@@ -292,12 +307,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p
     for (int i = 0; i < TM; ++i) {
         // issue this pass's global loads first: they fly while the accumulators go through LDS
         constexpr int NIT = 32 / RPI;
+        const int gmb = __builtin_amdgcn_readfirstlane(m0 + wm * (BM / WM) + i * 32);
+        const int gmbc = min(gmb, p.M - 1);      // edge tiles: a wave's rows may all lie past M
         f32x4 ext[NIT];
         float rs[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int gmc = min(m0 + wm * (BM / WM) + i * 32 + it * RPI + rrow, p.M - 1);
-            ext[it] = epilogue_ext<T, EPI>(p, gmc, gnc);
+            const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
+            const int gmc = gmbc + rowc;
+            ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
             rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[p.e.row_index ? p.e.row_index[gmc] : gmc] : 1.f;
         }
 #pragma unroll
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + rrow;
-            const int gm = m0 + wm * (BM / WM) + i * 32 + row;
+            const int gm = gmb + row;
             if constexpr (EPI == EPI_ARGMAX) {
                 // fused arg-max over the vocabulary (modeling_discrete_vae.py:246-248): per row, the best
                 // (value, index) of this wave's ROWF columns -> partial[gm][chunk]; logits never reach HBM
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p
                     ((int*)pv)[1] = bi;
                 }
             } else {
-                if (gm < p.M && col_ok) epilogue4<T, EPI>(p, gm, gn, v[it], bias4, gamma4, ext[it], rs[it]);
+                if (gm < p.M && col_ok) epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
