@@ -98,6 +98,23 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
     return 0;
 }
 
+extern "C" int vlmo_side_stream_create(int low_priority, const uint32_t* cu_mask, int cu_mask_words, hipStream_t* out) {
+    VLMO_CHECK_ARG(out, "vlmo_side_stream_create: null out");
+    hipError_t rc;
+    if (cu_mask && cu_mask_words > 0) {
+        rc = hipExtStreamCreateWithCUMask(out, (uint32_t)cu_mask_words, cu_mask);
+    } else {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        rc = hipStreamCreateWithPriority(out, hipStreamNonBlocking, low_priority ? least : 0);
+    }
+    if (rc != hipSuccess) {
+        vlmo_set_error("vlmo_side_stream_create: %s", hipGetErrorString(rc));
+        return (int)rc;
+    }
+    return 0;
+}
+
 extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     VLMO_CHECK_ARG(b && b->dx2 && b->dx1 && b->dx0, "vlmo_block_bwd: null descriptor/buffers");
     const int M = b->M, d = b->d, hid = b->hidden;

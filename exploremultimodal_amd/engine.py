@@ -19,7 +19,7 @@ LN_EPS = 1e-12          # vlmo_module.py:21-23
 GRAD_SINK = None         # set by dp.GradReducer: block gradients are accumulated straight into its flat buckets
 import os as _os
 OVERLAP_WGRAD = _os.environ.get('VLMO_OVERLAP_WGRAD', '1') != '0'   # weight-gradient GEMMs + bias column sums on a side stream
-SIDE_PRIORITY = int(_os.environ.get('VLMO_SIDE_PRIORITY', '0'))
+SIDE_MODE = _os.environ.get('VLMO_SIDE_STREAM', 'low')
 DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
 
@@ -152,9 +152,17 @@ _SIDE = {}
 
 
 def _side_stream(dev):
+    """The weight-gradient stream of a device: lowest dispatch priority, so the activation-gradient chain
+    on the caller's stream (the critical path) wins every freed compute-unit slot.  VLMO_SIDE_STREAM=
+    'low' (default) | 'normal' | 'cumask:<hex words, comma separated>' (measurement aid)."""
     s = _SIDE.get(dev)
     if s is None:
-        s = torch.cuda.Stream(device=dev, priority=SIDE_PRIORITY)
+        with torch.cuda.device(dev):
+            if SIDE_MODE.startswith('cumask:'):
+                raw = hip.side_stream_create(False, [int(w, 16) for w in SIDE_MODE[7:].split(',')])
+            else:
+                raw = hip.side_stream_create(SIDE_MODE != 'normal')
+        s = torch.cuda.ExternalStream(raw, device=dev)
         _SIDE[dev] = s
     return s
 

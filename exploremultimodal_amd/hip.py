@@ -83,6 +83,7 @@ _SIGS = {
     'vlmo_block_fwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_block_bwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_profile_start': [_i32],
+    'vlmo_side_stream_create': [_i32, ctypes.POINTER(ctypes.c_uint32), _i32, ctypes.POINTER(ctypes.c_void_p)],
     'vlmo_profile_stop': [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                           ctypes.POINTER(ctypes.c_int64)],
 }
@@ -325,6 +326,19 @@ def block_bwd(desc):
 
 
 PROFILE_TAGS = 80
+
+
+def side_stream_create(low_priority=True, cu_mask=None):
+    """Native stream for the weight-gradient work (include/vlmo_hip.h: vlmo_side_stream_create) -> raw
+    hipStream_t value.  Create it with the target device current."""
+    out = ctypes.c_void_p()
+    if cu_mask:
+        words = (ctypes.c_uint32 * len(cu_mask))(*cu_mask)
+        rc = lib().vlmo_side_stream_create(0, words, len(cu_mask), ctypes.byref(out))
+    else:
+        rc = lib().vlmo_side_stream_create(1 if low_priority else 0, None, 0, ctypes.byref(out))
+    _check(rc, 'vlmo_side_stream_create')
+    return out.value
 
 
 def profile_start(max_records=1 << 15):

@@ -159,6 +159,12 @@ int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, c
 int vlmo_profile_start(int max_records);
 int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches);
 
+/* The stream vlmo_block_bwd's weight-gradient work runs on (VlmoBlockDesc.side_stream).  It has the
+ * whole step of slack while the activation-gradient chain on the caller's stream is the critical
+ * path, so it is created with the LOWEST dispatch priority of the device (low_priority != 0), and/or
+ * confined to the compute units of cu_mask (cu_mask_words 32-bit words; NULL/0 = all CUs). */
+int vlmo_side_stream_create(int low_priority, const uint32_t* cu_mask, int cu_mask_words, hipStream_t* out);
+
 /* ---- one transformer Block in ONE call (vlmo.py:187-197 and its autograd) ---------------------
  * Enqueues norm1 -> qkv -> attention -> proj(+gamma_1, residual) -> norm2 -> expert FFN(s)
  * (+gamma_2, residual), resp. the whole backward of that, from native code: the host pays one
