@@ -90,8 +90,8 @@ def cpu_baseline(preset, B=8, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (pairs)')
     ap.add_argument('--preset', default='base')
     ap.add_argument('--tile', type=int, default=None)

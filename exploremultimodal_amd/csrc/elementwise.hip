@@ -383,7 +383,15 @@ __global__ __launch_bounds__(256) void embed_txt_bwd_kernel(const float* __restr
 
 }  // namespace
 
+thread_local PartialReduce* vlmo_defer_reduce = nullptr;
+
 int reduce_partials(const float* ws, int nblk, int ncols, float* out0, int n0, float* out1, hipStream_t stream) {
+    if (vlmo_defer_reduce) {
+        PartialReduce* r = vlmo_defer_reduce;
+        vlmo_defer_reduce = nullptr;
+        r->ws = ws, r->nblk = nblk, r->ncols = ncols, r->out0 = out0, r->n0 = n0, r->out1 = out1;
+        return 0;
+    }
     int slices = nblk >= 64 ? 8 : 1;
     const int rps = (nblk + slices - 1) / slices;
     slices = (nblk + rps - 1) / rps;

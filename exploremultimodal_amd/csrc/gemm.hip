@@ -160,7 +160,7 @@ template <int BK> __device__ __forceinline__ int nt_swz(int row) {
     return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK, int NSTG>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK, int NSTG, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p) {
     typedef typename Elem<T>::v8 v8;
     constexpr int NW = WM * WN;
@@ -260,7 +260,66 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
     };
-    if constexpr (NSTG == 2) {
+    if constexpr (PP) {
+        // Ping-pong schedule (8 waves, WM == 2): every K-tile is four segments separated by raw
+        // s_barriers -- read fragments of k-half 0 | 16 MFMAs | read k-half 1 | 16 MFMAs -- and the
+        // wm == 1 waves run ONE segment behind the wm == 0 waves (one extra barrier up front, one
+        // at the end for wm == 0).  A SIMD hosts one wave of each group, so while one multiplies the
+        // other reads LDS: the MFMA pipe and the LDS port are both busy all the time instead of
+        // taking turns.  The LDS-DMA of tile t+1 is issued at the start of the first MFMA segment of
+        // tile t (all reads of that buffer retired >= 1 barrier earlier) and waited for, by the
+        // issuing wave, in its segment before the barrier that opens tile t+1 for the leading group.
+        static_assert(NSTG == 2 && WM == 2 && KS == 4, "ping-pong schedule: 2 buffers, 2 row groups, BK = 64");
+        v8 af[2][TM], bf[2][TN];
+        auto read_half = [&](const char* s_, int hf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int coff = ((2 * (2 * hf + q) + h) ^ swz) << 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[q][i] = *(const v8*)(s_ + a_row_off + i * 32 * ROWB + coff);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[q][j] = *(const v8*)(s_ + b_row_off + j * 32 * ROWB + coff);
+            }
+        };
+        auto mfma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[q][i], bf[q][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {      // raw barrier: no vmcnt drain; nothing may be scheduled across it
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) bar();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* cur = smem + (kt & 1) * STAGE;
+            const bool more = kt + 1 < nk;
+            read_half(cur, 0);
+            bar();
+            if (more) stage((kt + 1) & 1, kt + 1);
+            mfma_half();
+            bar();
+            read_half(cur, 1);
+            if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+            mfma_half();
+            if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+        }
+        if (wm == 0) bar();
+    } else {
+        static_assert(NSTG == 2, "two LDS buffers");
         // 2-deep ring: one K-tile in flight behind the one being multiplied
         stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -268,26 +327,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p
             __syncthreads();
             if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
             compute(smem + (kt & 1) * STAGE);
-        }
-    } else {
-        // NSTG-deep ring, NSTG-1 K-tiles in flight: counted vmcnt + raw s_barrier so the LDS-DMA of the
-        // younger tiles stays in flight across the barrier (a __syncthreads() would drain it)
-        constexpr int LPS = NA + NB;      // LDS-DMA instructions per wave per K-tile
-#pragma unroll
-        for (int q = 0; q < NSTG - 1; ++q)
-            if (q < nk) stage(q, q);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int younger = min(NSTG - 2, nk - 1 - kt);     // K-tiles issued after tile kt
-            if (younger >= 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            } else if (younger == 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (kt + NSTG - 1 < nk) stage((kt + NSTG - 1) % NSTG, kt + NSTG - 1);
-            compute(smem + (kt % NSTG) * STAGE);
         }
     }
 
@@ -376,7 +415,7 @@ struct GemmTN {
     const void* B;   // [M, ldb], uses columns [0, N2)
     float* C;        // [N1, ldc] fp32, atomically accumulated
     int M, N1, N2, lda, ldb, ldc;
-    int kt_per_split;
+    int kt_per_split, tiles;
     float alpha;
     float* slab;     // [splits, N1, N2] fp32 partial products (plain stores) or NULL (atomics into C)
 };
@@ -386,7 +425,7 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row
 
 // Output tile BM x BN (multiples of 128) per workgroup of WM x WN waves; each operand's K-tile (64 token rows)
 // is staged as BM/128 resp. BN/128 side-by-side sub-images of [64 rows][128 columns] in the dual-use swizzle.
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p) {
     typedef typename Elem<T>::v8 v8;
     typedef typename Elem<T>::v4 v4;
@@ -401,10 +440,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    // 1-D grid of splits x tiles, remapped so that the workgroups one XCD runs are consecutive
+    // (split-major): the ~32 tiles of one K-split share that split's token rows through the XCD's L2
     const int tiles_n = (p.N2 + BN - 1) / BN;
-    const int n1_0 = (blockIdx.x / tiles_n) * BM, n2_0 = (blockIdx.x % tiles_n) * BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / p.tiles, tile = lid - split * p.tiles;
+    const int n1_0 = (tile / tiles_n) * BM, n2_0 = (tile % tiles_n) * BN;
     const int nk_total = (p.M + 63) >> 6;
-    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
     if (kt0 >= kt1) return;
 
@@ -452,49 +495,97 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p
     const int ncol_a = wm * (BM / WM) + 16 * (g & 1) + 4 * pp;   // + tile*32
     const int ncol_b = wn * (BN / WN) + 16 * (g & 1) + 4 * pp;
 
-    stage(0, kt0);
-    for (int kt = kt0; kt < kt1; ++kt) {
+    // fragments of one 16-row k-step ks of the K-tile in image s_ (rows >= M were loaded from the clamped
+    // last row: one operand is zeroed there)
+    auto read_step = [&](const char* s_, int kt, int ks, v8* af, v8* bf) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int m = 16 * ks + 8 * h + 4 * half + q;
+            const int sw = tn_swz(m);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int na = ncol_a + t * 32;
+                const v4 va = lds_tr4<T>(s_ + (na >> 7) * SUB + m * 256 + ((((na & 127) >> 3) ^ sw) << 4) + (na & 7) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) af[t][4 * half + e] = va[e];
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int nb = ncol_b + t * 32;
+                const v4 vb = lds_tr4<T>(s_ + A_BYTES + (nb >> 7) * SUB + m * 256 + ((((nb & 127) >> 3) ^ sw) << 4) + (nb & 7) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bf[t][4 * half + e] = vb[e];
+            }
+        }
+        if (kt * 64 + 64 > p.M) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = (kt * 64 + 16 * ks + 8 * h + e) < p.M;
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    if (!ok) af[t][e] = (T)0.f;
+            }
+        }
+    };
+    if constexpr (PP) {
+        // ping-pong schedule: see gemm_nt_kernel (wm == 1 waves run one segment behind wm == 0)
+        static_assert(WM == 2, "ping-pong schedule needs two row groups");
+        v8 af[2][TM], bf[2][TN];
+        auto mfma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[u][i], bf[u][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage(0, kt0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < kt1) stage((kt - kt0 + 1) & 1, kt + 1);
-        const char* s = smem + ((kt - kt0) & 1) * STAGE;
-        const bool tail = (kt * 64 + 64 > p.M);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) bar();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const char* cur = smem + ((kt - kt0) & 1) * STAGE;
+            const bool more = kt + 1 < kt1;
+            read_step(cur, kt, 0, af[0], bf[0]);
+            read_step(cur, kt, 1, af[1], bf[1]);
+            bar();
+            if (more) stage((kt - kt0 + 1) & 1, kt + 1);
+            mfma_half();
+            bar();
+            read_step(cur, kt, 2, af[0], bf[0]);
+            read_step(cur, kt, 3, af[1], bf[1]);
+            if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+            mfma_half();
+            if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+        }
+        if (wm == 0) bar();
+    } else {
+        stage(0, kt0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < kt1) stage((kt - kt0 + 1) & 1, kt + 1);
+            const char* s = smem + ((kt - kt0) & 1) * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            v8 af[TM], bf[TN];
+            for (int ks = 0; ks < 4; ++ks) {
+                v8 af[TM], bf[TN];
+                read_step(s, kt, ks, af, bf);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int m = 16 * ks + 8 * h + 4 * half + q;
-                const int sw = tn_swz(m);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int t = 0; t < TM; ++t) {
-                    const int na = ncol_a + t * 32;
-                    const v4 va = lds_tr4<T>(s + (na >> 7) * SUB + m * 256 + ((((na & 127) >> 3) ^ sw) << 4) + (na & 7) * 2);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) af[t][4 * half + e] = va[e];
-                }
-#pragma unroll
-                for (int t = 0; t < TN; ++t) {
-                    const int nb = ncol_b + t * 32;
-                    const v4 vb = lds_tr4<T>(s + A_BYTES + (nb >> 7) * SUB + m * 256 + ((((nb & 127) >> 3) ^ sw) << 4) + (nb & 7) * 2);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bf[t][4 * half + e] = vb[e];
-                }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
             }
-            if (tail) {
-                // rows >= M were loaded from the clamped last row: zero one operand
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool ok = (kt * 64 + 16 * ks + 8 * h + e) < p.M;
-#pragma unroll
-                    for (int t = 0; t < TM; ++t)
-                        if (!ok) af[t][e] = (T)0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
         }
     }
     // epilogue: lane = output column, register = output row: each half-wave
@@ -510,7 +601,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p
                 const int gm = n1_0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (gm < p.N1 && gn < p.N2) {
                     if (p.slab)
-                        p.slab[((size_t)blockIdx.y * p.N1 + gm) * p.N2 + gn] = acc[i][j][r];
+                        p.slab[((size_t)split * p.N1 + gm) * p.N2 + gn] = acc[i][j][r];
                     else
                         atomicAdd(p.C + (size_t)gm * p.ldc + gn, p.alpha * acc[i][j][r]);
                 }
@@ -532,14 +623,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV = false, int BK = 64, int NSTG = 2>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV = false, int BK = 64, int NSTG = 2, bool PP = false>
 int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr int LDS = NSTG * (BM + BN) * BK * 2;
     dim3 grid(tiles), block(WM * WN * 64);
 #define VLMO_LAUNCH_EPI(E)                                                                     \
     case E: {                                                                                  \
-        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV, BK, NSTG>;                                         \
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV, BK, NSTG, PP>;                                        \
         if (LDS > 65536) {                                                                     \
             static bool attr_set = false;                                                      \
             if (!attr_set) {                                                                   \
@@ -665,20 +756,19 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     GemmNT p{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, 8};
     if (const char* sv = getenv("VLMO_GROUP_M")) p.group_m = atoi(sv);
     if (tile < 0) {
-        // measured on MI355X (tools/gemm_bench.py): deep reductions are load-latency bound and want the
-        // 2x higher arithmetic intensity of the 256x256 tile (one workgroup/CU); shallow ones (K = d) are
-        // epilogue bound and want two 128x128 workgroups per CU so one's stores overlap the other's MFMAs
+        // measured on MI355X (tools/gemm_bench.py): deep reductions want the 256x256 ping-pong kernel (half
+        // the staged bytes per flop, MFMA pipe and LDS port busy at the same time, one workgroup/CU);
+        // shallow ones (K = d) are epilogue bound and want two 128x128 workgroups per CU so that one's
+        // stores overlap the other's MFMAs
         tile = (K >= 1536 && M >= 2048 && N >= 512) ? 3 : 0;
     }
     ProfScope prof(epi + (tile == 3 ? 8 : 0), 2.0 * M * N * K, stream);
+    VLMO_CHECK_ARG(tile == 0 || tile == 3, "vlmo_gemm_nt: tile must be -1, 0 or 3 (got %d)", tile);
     if (dtype == VLMO_F16) {
-        if (tile == 1) return launch_nt<f16, 256, 128, 4, 2>(epi, p, stream);
-        if (tile == 3) return launch_nt<f16, 256, 256, 2, 4>(epi, p, stream);
+        if (tile == 3) return launch_nt<f16, 256, 256, 2, 4, false, 64, 2, true>(epi, p, stream);
         return launch_nt<f16, 128, 128, 2, 2>(epi, p, stream);
     }
-    if (tile == 1) return launch_nt<bf16, 256, 128, 4, 2>(epi, p, stream);
-    if (tile == 2) return launch_nt<bf16, 128, 128, 2, 2, false, 32, 4>(epi, p, stream);
-    if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4>(epi, p, stream);
+    if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4, false, 64, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
 }
 
@@ -737,21 +827,21 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     // big enough and there is more than one split; else straight into C with fp32 atomics.  Measured on MI355X:
     // 7 splits of a 3072x768 gradient as atomics cost ~30 us of a 135 us launch (memory-side atomic rate).
     const bool use_slab = ws && pl.splits > 1 && N2 % 4 == 0 && ldc % 4 == 0 && ws_bytes >= (int64_t)pl.splits * N1 * N2 * 4;
-    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, pl.per, alpha, use_slab ? ws : nullptr};
-    dim3 grid(pl.tiles, pl.splits);
+    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, pl.per, pl.tiles, alpha, use_slab ? ws : nullptr};
+    dim3 grid(pl.tiles * pl.splits);
     ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
     if (pl.big) {
         constexpr int LDS = 2 * 4 * 64 * 256;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16, 256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             attr = true;
         }
         if (dtype == VLMO_F16)
-            hipLaunchKernelGGL((gemm_tn_kernel<f16, 256, 256, 2, 4>), grid, dim3(512), LDS, stream, p);
+            hipLaunchKernelGGL((gemm_tn_kernel<f16, 256, 256, 2, 4, true>), grid, dim3(512), LDS, stream, p);
         else
-            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4>), grid, dim3(512), LDS, stream, p);
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4, true>), grid, dim3(512), LDS, stream, p);
     } else {
         if (dtype == VLMO_F16)
             hipLaunchKernelGGL((gemm_tn_kernel<f16, 128, 128, 2, 2>), grid, dim3(256), 65536, stream, p);

@@ -316,7 +316,8 @@ class BlockFn(torch.autograd.Function):
         D.dz2, D.du, D.dy2, D.dz1, D.dqkv, D.dy1 = pb, pb + md2, pb + 5 * md2, pb + 6 * md2, pb + 7 * md2, pb + 10 * md2
         D.dctx = D.dy2      # dy2 is consumed by ln_bwd on the main stream before dctx is written; never read on the side
         D.dx2, D.dx1, D.dx0 = dx2.data_ptr(), dx1.data_ptr(), dx0.data_ptr()
-        ncols = max(3 * d, hid)
+        # column-partial workspace: one 2d-wide slot per deferred fold of vlmo_block_bwd (3 + experts of them)
+        ncols = max(3 * d, hid, 2 * d * (3 + len(meta.expert_ranges)))
         ws_main = hip.workspace(dev, ncols)
         D.ws_main, D.ws_bytes = ws_main.data_ptr(), ws_main.numel() * 4
         side = _side_stream(dev) if OVERLAP_WGRAD else None

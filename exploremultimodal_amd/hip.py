@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvlmo_hip.so')
+# VLMO_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants in one GPU session)
+LIB_PATH = os.environ.get('VLMO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvlmo_hip.so')
 
 BF16, F16, F32 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32, EPI_DUAL, EPI_ARGMAX = 0, 1, 2, 3, 4, 5, 6

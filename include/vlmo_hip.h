@@ -68,8 +68,8 @@ typedef struct VlmoEpilogue {
 const char* vlmo_last_error(void);
 int vlmo_abi_version(void);
 
-/* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  tile: -1 = pick by shape, 0 = 128x128x64,
- * 1 = 256x128x64, 2 = 128x128x32 with a 4-deep ring (counted vmcnt), 3 = 256x256x64.
+/* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  tile: -1 = pick by shape, 0 = 128x128x64
+ * (two workgroups per CU), 3 = 256x256x64 with the two-wave-group ping-pong schedule (one per CU).
  * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm
  * Mlp fc1/fc2 (vlmo.py:141-157, 195-196), the PatchEmbed conv (vlmo.py:304) and,
  * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */

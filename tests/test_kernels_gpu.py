@@ -32,7 +32,7 @@ def _close(got, ref, rtol, atol, what=''):
             f'first at {idx}: got {got[tuple(idx)].item():.6g} ref {ref[tuple(idx)].item():.6g}')
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('tile', [0, 3])
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (300, 256, 128), (1000, 384, 768), (77, 128, 192)])
 def test_gemm_nt_exact_integers(tile, M, N, K):
     """Asymmetric small-integer operands: products and fp32 sums are exact, so any
@@ -49,7 +49,7 @@ def test_gemm_nt_exact_integers(tile, M, N, K):
     assert torch.equal(out.cpu(), ref), (out.cpu() - ref).abs().max()
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('tile', [0, 3])
 def test_gemm_nt_bias_bf16_and_padding_rows(tile):
     M, N, K = 333, 256, 256
     A, B = _rand(M, K, seed=1), _rand(N, K, scale=0.1, seed=2)
