@@ -24,7 +24,10 @@ inline char* bp(void* p, size_t row, size_t ld, size_t esz) { return (char*)p + 
 #define TRY(x)              \
     do {                    \
         int rc__ = (x);     \
-        if (rc__) return rc__; \
+        if (rc__) {         \
+            vlmo_defer_reduce = nullptr; \
+            return rc__;    \
+        }                   \
     } while (0)
 
 VlmoEpilogue epi() {
@@ -127,14 +130,23 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
             (void)hipStreamWaitEvent(side, ev.fork, 0);
         }
     };
+    // The column folds of the LayerNorm / LayerScale / bias gradients are deferred to the side stream (after
+    // the next fork) when the workspace has a slot per producer; else they run in place on the main stream.
+    const int64_t slot = reduce_ws_need(2 * d);
+    const bool defer = side != st && b->ws_bytes >= (int64_t)(3 + b->n_experts) * slot && b->n_experts <= 3;
+    auto ws_slot = [&](int k) { return defer ? (float*)((char*)b->ws_main + k * slot) : b->ws_main; };
+    PartialReduce pend[6];
+    auto arm = [&](int k) { vlmo_defer_reduce = defer ? &pend[k] : nullptr; };
     // ---- FFN half
     for (int x = 0; x < b->n_experts; ++x) {
         const size_t r0 = b->exp_row0[x];
         const int n = b->exp_rows[x];
+        arm(2 + x);
         TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2,
                            b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr),
                            b->row_index ? b->row_index + r0 : nullptr, bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d, b->drop_thresh, b->inv_keep,
-                           b->seed + 21 + 2 * x, b->ws_main, b->ws_bytes, st));
+                           b->seed + 21 + 2 * x, ws_slot(2 + x), slot, st));
+        vlmo_defer_reduce = nullptr;
         VlmoEpilogue e = epi();
         e.out = bp(b->du, r0, hid, 2);
         e.ldo = hid;
@@ -145,6 +157,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.seed = b->seed + 20 + 2 * x;
         TRY(vlmo_gemm_nt(VLMO_EPI_DGELU, VLMO_BF16, b->tile, bp(b->dz2, r0, d, 2), d, b->w2T[x], d, n, hid, d, &e, st));
         fork();
+        TRY(reduce_partials(pend[2 + x], side));
         TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
         TRY(vlmo_colsum(VLMO_BF16, bp(b->du, r0, hid, 2), hid, b->db1[x], n, hid, ws_side, b->ws_bytes, side));
         TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
@@ -153,25 +166,30 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         f.ldo = d;
         TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, bp(b->du, r0, hid, 2), hid, b->w1T[x], hid, n, d, hid, &f, st));
     }
+    arm(0);
     TRY(vlmo_ln_bwd(b->dy2, 0, nullptr, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, M, d,
-                    b->ws_main, b->ws_bytes, st));
+                    ws_slot(0), slot, st));
+    vlmo_defer_reduce = nullptr;
     // ---- attention half
+    arm(1);
     TRY(vlmo_resid_bwd(b->dx1, b->zd1, b->g1, b->rs1, b->row_index, b->dz1, b->dg1, b->dproj_b, M, d, b->drop_thresh, b->inv_keep,
-                       b->seed + 1, b->ws_main, b->ws_bytes, st));
+                       b->seed + 1, ws_slot(1), slot, st));
+    vlmo_defer_reduce = nullptr;
     {
         VlmoEpilogue e = epi();
         e.out = b->dctx;
         e.ldo = d;
         TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dz1, d, b->proj_wT, d, M, d, d, &e, st));
     }
-    fork();
-    TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     const float scale = 1.0f / sqrtf((float)(d / b->heads));
     for (int a = 0; a < b->n_attn; ++a)
         TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
                           b->dqkv, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
                           b->seed + 11 + a, st));
-    fork();
+    fork();     // one fork for the whole attention half: the proj gradient waits for it too (the side stream has slack)
+    TRY(reduce_partials(pend[0], side));
+    TRY(reduce_partials(pend[1], side));
+    TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     TRY(vlmo_colsum(VLMO_BF16, b->dqkv, 3 * d, b->dqkv_b, M, 3 * d, ws_side, b->ws_bytes, side));
     TRY(vlmo_gemm_tn(VLMO_BF16, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     {
@@ -180,8 +198,10 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.ldo = d;
         TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dqkv, 3 * d, b->qkv_wT, 3 * d, M, d, 3 * d, &e, st));
     }
+    // the last fold stays on the main stream (a fork for it would cost what it saves); its own slot: the
+    // side stream may still be reading slot 0
     TRY(vlmo_ln_bwd(b->dy1, 0, nullptr, b->x, b->n1w, b->mean1, b->rstd1, b->dx1, b->dx0, b->dn1w, b->dn1b, M, d,
-                    b->ws_main, b->ws_bytes, st));
+                    ws_slot(2 + b->n_experts), slot, st));
     if (side != st) {       // join: gradients complete, every buffer the side stream read is reusable
         (void)hipEventRecord(ev.join, side);
         (void)hipStreamWaitEvent(st, ev.join, 0);
