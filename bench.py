@@ -95,6 +95,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (pairs)')
     ap.add_argument('--preset', default='base')
     ap.add_argument('--tile', type=int, default=None)
+    ap.add_argument('--optimizer', action='store_true',
+                    help='also run the fused AdamW step with global-norm clip 5.0 (conf/train/pretrain_mum.yaml:28-36,54,75-80) '
+                         'inside the timed step; the headline metric is forward+backward only, so this is off by default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropout', action='store_true')
     ap.add_argument('--force-reducer', action='store_true', help='run the RCCL gradient reducer even at world size 1')
@@ -149,6 +152,15 @@ def main():
     imask = torch.ones(B, P, dtype=torch.int64, device=dev)
     R = torch.randn(B, mc.max_text_len + P, mc.embed_dim, device=dev) / (B * 1000.0)
 
+    opt = None
+    if args.optimizer:
+        from types import SimpleNamespace as NS
+        from exploremultimodal_amd import optim
+        if not hasattr(model, 'config'):      # bare VLMO backbone: give the factory the attributes it reads by name
+            model.config = NS(model=mc)
+        opt = optim.create_optimizer(NS(opt=NS(name='fusedadamw', eps=1e-8, betas=[0.9, 0.98], momentum=0.9), weight_decay=0.01,
+                                        base_lr=2e-4, lr_mult_head=1, lr_mult_fusion=1), model)
+
     def step():
         for p in model.parameters():
             p.grad = None
@@ -163,6 +175,8 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.finish()
+        if opt is not None:
+            opt.step(clip_grad=5.0)
         return loss
 
     def barrier():
@@ -237,7 +251,8 @@ def main():
                                     f'VLMo-{args.preset} VlmoModule.forward [mlm,mim,itc,itm] + in-loop dVAE, fwd+bwd'
                                     + (', ZeRO-2 grad partition' if args.zero2 else '')) +
                                    f', per-GPU batch {B} synthetic 224x224 image + {mc.max_text_len}-token text '
-                                   f'pairs, dropout/drop-path {0.0 if args.no_dropout else 0.1}',
+                                   f'pairs, dropout/drop-path {0.0 if args.no_dropout else 0.1}'
+                                   + (', + fused AdamW step with clip 5.0' if args.optimizer else ''),
                        'global_batch': B * world, 'seq_len': mc.max_text_len + P,
                        'parallelism': f'dp{world}'},
             'step_tflops': round(fl * B * world * args.steps / dt / 1e12, 1),

@@ -84,6 +84,8 @@ _SIGS = {
     'vlmo_block_fwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_block_bwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_profile_start': [_i32],
+    'vlmo_mt_grad_norm': [ctypes.c_void_p, _f32, _f32, _vp, _vp, _vp],
+    'vlmo_mt_adam': [ctypes.c_void_p, ctypes.c_void_p, _vp, _vp],
     'vlmo_side_stream_create': [_i32, ctypes.POINTER(ctypes.c_uint32), _i32, ctypes.POINTER(ctypes.c_void_p)],
     'vlmo_profile_stop': [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                           ctypes.POINTER(ctypes.c_int64)],
@@ -327,6 +329,27 @@ def block_bwd(desc):
 
 
 PROFILE_TAGS = 80
+
+
+class TensorList(ctypes.Structure):
+    """VlmoTensorList (include/vlmo_hip.h): device tables of one multi-tensor optimizer launch."""
+    _fields_ = [('p', _vp), ('g', _vp), ('m', _vp), ('v', _vp), ('numel', _vp), ('lr', _vp), ('wd', _vp),
+                ('chunk_tensor', _vp), ('chunk_start', _vp), ('n_chunks', _i32), ('chunk', _i32)]
+
+
+class AdamArgs(ctypes.Structure):
+    _fields_ = [('beta1', _f32), ('beta2', _f32), ('eps', _f32), ('inv_bc1', _f32), ('inv_bc2', _f32),
+                ('adam_w_mode', _i32)]
+
+
+def mt_grad_norm(tl, inv_scale, max_norm, partial, out):
+    """out[0] = grad norm, out[1] = factor for the raw gradients, out[2] = non-finite flag (device floats)."""
+    _check(lib().vlmo_mt_grad_norm(ctypes.byref(tl), float(inv_scale), float(max_norm), _p(partial), _p(out), _stream()),
+           'vlmo_mt_grad_norm')
+
+
+def mt_adam(tl, args, ctl=None):
+    _check(lib().vlmo_mt_adam(ctypes.byref(tl), ctypes.byref(args), _p(ctl), _stream()), 'vlmo_mt_adam')
 
 
 def side_stream_create(low_priority=True, cu_mask=None):

@@ -159,6 +159,40 @@ int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, c
 int vlmo_profile_start(int max_records);
 int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches);
 
+/* ---- optimizer step ---------------------------------------------------------------
+ * Multi-tensor Adam / AdamW over a list of fp32 tensors, replacing apex FusedAdam(adam_w_mode=True)
+ * (utils/optim_factory.py:185-186) and the unscale + clip_grad_norm_ of NativeScalerWithGradNormCount
+ * (utils/utils.py:343-364).  All tables are DEVICE arrays owned by the caller: per tensor the device
+ * addresses of parameter / gradient / exp_avg / exp_avg_sq, its element count, learning rate and weight
+ * decay; the work list is cut into chunks of `chunk` elements (chunk_tensor[c], chunk_start[c]). */
+typedef struct {
+    const int64_t* p;
+    const int64_t* g;
+    const int64_t* m;
+    const int64_t* v;
+    const int64_t* numel;
+    const float* lr;
+    const float* wd;
+    const int32_t* chunk_tensor;
+    const int64_t* chunk_start;
+    int32_t n_chunks, chunk;
+} VlmoTensorList;
+
+typedef struct {
+    float beta1, beta2, eps;
+    float inv_bc1, inv_bc2;     /* 1 / (1 - beta^step), or 1 without bias correction */
+    int32_t adam_w_mode;        /* 1: decoupled weight decay (AdamW); 0: L2 (decay added to the gradient) */
+} VlmoAdamArgs;
+
+/* out[0] = || inv_scale * g ||_2 over every tensor of the list, out[1] = the factor to apply to the raw
+ * gradients = inv_scale * min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_; max_norm <= 0:
+ * no clipping), out[2] = 1 if the norm is not finite.  partial: n_chunks floats of scratch.  Deterministic. */
+int vlmo_mt_grad_norm(const VlmoTensorList* tl, float inv_scale, float max_norm, float* partial, float* out,
+                      hipStream_t stream);
+/* One Adam step on every tensor.  ctl = the 3 floats of vlmo_mt_grad_norm (gradients are multiplied by
+ * ctl[1]; the whole step is skipped when ctl[2] != 0, like GradScaler.step) or NULL. */
+int vlmo_mt_adam(const VlmoTensorList* tl, const VlmoAdamArgs* a, const float* ctl, hipStream_t stream);
+
 /* The stream vlmo_block_bwd's weight-gradient work runs on (VlmoBlockDesc.side_stream).  It has the
  * whole step of slack while the activation-gradient chain on the caller's stream is the critical
  * path, so it is created with the LOWEST dispatch priority of the device (low_priority != 0), and/or

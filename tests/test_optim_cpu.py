@@ -1,0 +1,100 @@
+"""Host logic of the optimizer side (no GPU): name-based parameter groups (utils/optim_factory.py:22-90), factory
+dispatch (optim_factory.py:93-199), the cosine schedule table (utils/utils.py:399-424) and the fp64 AdamW oracle
+against torch.optim.AdamW on CPU."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from exploremultimodal_amd import optim
+from exploremultimodal_amd.build import build_model
+from oracle import adamw_oracle, synth
+
+
+def _model():
+    cfg = synth.make_config('mini', loss_names=['mlm', 'itc', 'itm'])
+    return build_model(cfg), cfg
+
+
+def test_parameter_groups_follow_the_reference_name_rules():
+    model, cfg = _model()
+    skip = model.no_weight_decay()
+    groups = optim.get_parameter_groups(model, base_lr=1e-3, lr_mult_head=10, lr_mult_fusion=3, weight_decay=0.05,
+                                        skip_list=skip)
+    by_id = {}
+    for g in groups:
+        for p in g['params']:
+            by_id[id(p)] = g
+    F, L = cfg.model.fusion_layer, cfg.model.depth
+    n = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        n += 1
+        g = by_id[id(p)]
+        no_decay = p.dim() <= 1 or name.endswith('.bias') or name in skip
+        assert g['weight_decay'] == (0.0 if no_decay else 0.05), name
+        if any(h in name for h in ('mlm_head', 'itc_head', 'itm_head', 'mim_head')):
+            assert g['lr'] == pytest.approx(1e-2), name
+        elif any(f'blocks.{i}' in name for i in range(F, L)) or 'pooler' in name:
+            assert g['lr'] == pytest.approx(3e-3), name
+        else:
+            assert g['lr'] == pytest.approx(1e-3), name
+    assert n == sum(len(g['params']) for g in groups)
+    assert 4 <= len(groups) <= 6
+    # skip-list entries (pos_embed, img_cls_token, itc_temp) carry no decay even though pos_embed is 3-D
+    pe = dict(model.named_parameters())['transformer.pos_embed']
+    assert by_id[id(pe)]['weight_decay'] == 0.0
+
+
+def test_factory_dispatch():
+    model, _ = _model()
+    mk = lambda name: types.SimpleNamespace(opt=types.SimpleNamespace(name=name, eps=1e-8, betas=[0.9, 0.98], momentum=0.9),
+                                            weight_decay=0.01, base_lr=2e-4, lr_mult_head=1, lr_mult_fusion=1)
+    o = optim.create_optimizer(mk('fusedadamw'), model)
+    assert isinstance(o, optim.FusedAdam) and o.adam_w_mode == 1 and o.defaults['betas'] == (0.9, 0.98)
+    assert optim.create_optimizer(mk('adam'), model).adam_w_mode == 0
+    assert isinstance(optim.create_optimizer(mk('momentum'), model), torch.optim.SGD)
+    with pytest.raises(NotImplementedError):
+        optim.create_optimizer(mk('lookahead_adamw'), model)
+    with pytest.raises(NotImplementedError):
+        optim.create_optimizer(mk('fusedlamb'), model)
+    # no CPU fallback: stepping CPU parameters fails loudly
+    for p in model.parameters():
+        if p.requires_grad:
+            p.grad = torch.zeros_like(p)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        o.step()
+
+
+def test_cosine_scheduler_table():
+    s = optim.cosine_scheduler(2e-4, 1e-6, epochs=3, niter_per_ep=10, warmup_epochs=1, start_warmup_value=0.0)
+    assert len(s) == 30 and s[0] == 0.0 and s[9] == pytest.approx(2e-4) and s[10] == pytest.approx(2e-4)
+    assert s[-1] == pytest.approx(1e-6 + 0.5 * (2e-4 - 1e-6) * (1 + math.cos(math.pi * 19 / 20)))
+    assert np.all(np.diff(s[10:]) < 0)
+    s2 = optim.cosine_scheduler(1.0, 0.0, epochs=2, niter_per_ep=5, warmup_epochs=1, warmup_steps=3)
+    assert len(s2) == 10 and list(s2[:3]) == [0.0, 0.5, 1.0]
+
+
+@pytest.mark.parametrize('adam_w', [True, False])
+def test_oracle_matches_torch_adam_on_cpu(adam_w):
+    g = torch.Generator().manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(37, 5, generator=g, dtype=torch.float64))
+    ref = (torch.optim.AdamW if adam_w else torch.optim.Adam)([p], lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    o_p, o_m, o_v = p.detach().numpy().copy(), np.zeros((37, 5)), np.zeros((37, 5))
+    for step in range(1, 6):
+        gr = torch.randn(37, 5, generator=g, dtype=torch.float64)
+        p.grad = gr.clone()
+        ref.step()
+        o_p, o_m, o_v = adamw_oracle.adam_step(o_p, gr.numpy(), o_m, o_v, step, 3e-3, 0.9, 0.98, 1e-8, 0.1, adam_w_mode=adam_w)
+        np.testing.assert_allclose(p.detach().numpy(), o_p, rtol=1e-12, atol=1e-14)
+    grads = [torch.randn(11, generator=g).numpy(), torch.randn(3, 4, generator=g).numpy()]
+    ts = [torch.nn.Parameter(torch.zeros(11)), torch.nn.Parameter(torch.zeros(3, 4))]
+    for t, gr in zip(ts, grads):
+        t.grad = torch.from_numpy(gr.copy())
+    n_ref = torch.nn.utils.clip_grad_norm_(ts, 0.7)
+    n, c = adamw_oracle.clip_coef(grads, 0.7)
+    assert n == pytest.approx(n_ref.item(), rel=1e-6)
+    np.testing.assert_allclose(ts[0].grad.numpy(), grads[0] * c, rtol=1e-6)

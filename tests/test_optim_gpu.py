@@ -1,0 +1,141 @@
+"""Optimizer step: the HIP multi-tensor Adam / AdamW + fused clip against torch.optim.AdamW,
+torch.nn.utils.clip_grad_norm_ and the fp64 oracle.  Tolerance: fp32 round-off of a handful of fused
+multiply-adds, 2e-6 relative + 1e-7 absolute per step (written below)."""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from exploremultimodal_amd import optim
+from oracle import adamw_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _params(seed, shapes):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(DEV)) for s in shapes]
+
+
+SHAPES = [(300, 257), (1000,), (65536 + 3,), (7,), (64, 3, 16, 16), (1,), (131072,)]
+
+
+@pytest.mark.parametrize('adam_w', [True, False])
+def test_fused_adam_matches_torch_and_oracle(adam_w):
+    ps = _params(0, SHAPES)
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    groups = lambda xs: [{'params': xs[:3], 'lr': 2e-3, 'weight_decay': 0.05}, {'params': xs[3:], 'lr': 5e-4, 'weight_decay': 0.0}]
+    ours = optim.FusedAdam(groups(ps), betas=(0.9, 0.98), eps=1e-8, adam_w_mode=adam_w)
+    ref_cls = torch.optim.AdamW if adam_w else torch.optim.Adam
+    ref = ref_cls(groups(qs), betas=(0.9, 0.98), eps=1e-8)
+    # fp64 oracle state
+    o_p = [p.detach().cpu().double().numpy() for p in ps]
+    o_m = [np.zeros_like(x) for x in o_p]
+    o_v = [np.zeros_like(x) for x in o_p]
+    g = torch.Generator().manual_seed(1)
+    for step in range(1, 5):
+        grads = [torch.randn(p.shape, generator=g) * (0.1 * step) for p in ps]
+        for p, q, gr in zip(ps, qs, grads):
+            p.grad = gr.to(DEV)
+            q.grad = gr.to(DEV)
+        ours.step()
+        ref.step()
+        for i, gr in enumerate(grads):
+            lr, wd = (2e-3, 0.05) if i < 3 else (5e-4, 0.0)
+            o_p[i], o_m[i], o_v[i] = adamw_oracle.adam_step(o_p[i], gr.numpy(), o_m[i], o_v[i], step, lr, 0.9, 0.98, 1e-8, wd,
+                                                            adam_w_mode=adam_w)
+    for i, (p, q) in enumerate(zip(ps, qs)):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=2e-7)
+        err = np.abs(p.detach().cpu().double().numpy() - o_p[i]).max()
+        assert err <= 4 * (2e-6 * np.abs(o_p[i]).max() + 1e-7), (i, err)
+        st = ours.state[p]
+        assert int(st['step']) == 4 and st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape
+        np.testing.assert_allclose(st['exp_avg'].cpu().double().numpy(), o_m[i], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(st['exp_avg_sq'].cpu().double().numpy(), o_v[i], rtol=1e-5, atol=1e-10)
+
+
+@pytest.mark.parametrize('max_norm', [0.5, 1e9])
+def test_fused_clip_matches_clip_grad_norm(max_norm):
+    ps = _params(2, SHAPES)
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours = optim.FusedAdam(ps, lr=1e-3, weight_decay=0.01)
+    ref = torch.optim.AdamW(qs, lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        grads = [torch.randn(p.shape, generator=g) for p in ps]
+        for p, q, gr in zip(ps, qs, grads):
+            p.grad = gr.to(DEV)
+            q.grad = gr.to(DEV)
+        norm = ours.step(clip_grad=max_norm)
+        ref_norm = torch.nn.utils.clip_grad_norm_(qs, max_norm)
+        ref.step()
+        o_norm, o_coef = adamw_oracle.clip_coef([gr.numpy() for gr in grads], max_norm)
+        assert abs(norm.item() - o_norm) <= 1e-5 * o_norm
+        assert abs(ref_norm.item() - o_norm) <= 1e-5 * o_norm      # pins the oracle to torch's own clip
+        assert abs(ours.last_ctl[1].item() - o_coef) <= 1e-5 * o_coef
+        # .grad is left untouched by the fused path
+        torch.testing.assert_close(ps[0].grad.cpu(), grads[0])
+    for p, q in zip(ps, qs):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-5, atol=5e-7)
+
+
+def test_non_finite_gradients_skip_the_step():
+    ps = _params(4, [(100, 10), (33,)])
+    before = [p.detach().clone() for p in ps]
+    ours = optim.FusedAdam(ps, lr=1e-2)
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    ps[1].grad[5] = float('inf')
+    norm = ours.step(clip_grad=5.0)
+    assert not torch.isfinite(norm).item() and ours.last_ctl[2].item() == 1.0
+    for p, b in zip(ps, before):
+        assert torch.equal(p.detach(), b)
+    assert torch.count_nonzero(ours.state[ps[0]]['exp_avg']).item() == 0
+
+
+def test_state_dict_round_trip_and_torch_layout():
+    ps = _params(5, [(50, 20), (20,)])
+    ours = optim.FusedAdam(ps, lr=1e-2, weight_decay=0.1)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ours.step()
+    sd = copy.deepcopy(ours.state_dict())
+    assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    other = optim.FusedAdam(qs, lr=1e-2, weight_decay=0.1)
+    other.load_state_dict(sd)
+    for p, q in zip(ps, qs):
+        gr = torch.randn_like(p)
+        p.grad, q.grad = gr, gr.clone()
+    ours.step()
+    other.step()
+    for p, q in zip(ps, qs):
+        assert torch.equal(p.detach(), q.detach())
+
+
+def test_train_step_on_the_model_reduces_the_loss():
+    from exploremultimodal_amd.build import build_model
+    from oracle import synth
+    cfg = synth.make_config('mini', drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0)
+    model = build_model(cfg).to(DEV)
+    tcfg = types.SimpleNamespace(opt=types.SimpleNamespace(name='fusedadamw', eps=1e-8, betas=[0.9, 0.98], momentum=0.9),
+                                 weight_decay=0.01, base_lr=1e-3, lr_mult_head=1, lr_mult_fusion=1)
+    opt = optim.create_optimizer(tcfg, model)
+    assert isinstance(opt, optim.FusedAdam) and len(opt.param_groups) >= 4
+    scaler = optim.NativeScalerWithGradNormCount()
+    batch = synth.synth_batch(cfg.model, 4, seed=0)
+    img = batch['image'].to(DEV)
+    ids, tmask = batch['text_ids'].to(DEV), batch['text_mask'].to(DEV)
+    imask = torch.ones(4, (img.shape[-1] // cfg.model.patch_size) ** 2 + 1, dtype=torch.int64, device=DEV)
+    losses = []
+    for _ in range(8):
+        x, _ = model.transformer.forward_features(img=img, txt=ids, img_attn_masks=imask, txt_attn_masks=tmask)
+        loss = x.square().mean()
+        norm = scaler(loss, opt, clip_grad=5.0, parameters=model.parameters())
+        opt.zero_grad(set_to_none=True)
+        assert torch.isfinite(norm).item()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
