@@ -82,23 +82,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    for (int m = r0 + wave; m < r1; m += 4) {
+    // Everything a row needs from HBM (dy, x, the incoming residual gradient, mean/rstd) is fetched one row
+    // AHEAD of the arithmetic: beside the weight-gradient GEMMs of the side stream this kernel gets one or two
+    // waves per SIMD, so its speed is (bytes in flight per wave) / latency, not occupancy.
+    struct Row {
+        f32x4 dy[VPL], x[VPL], dr[VPL];
+        float mu, rs;
+    };
+    auto fetch = [&](int m, Row& r) {
         const int sm = rowmap ? rowmap[m] : m;
-        const float mu = mean[m], rs = rstd[m];
+        r.mu = mean[m];
+        r.rs = rstd[m];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                if constexpr (DY_F32) {
+                    r.dy[j] = ((const f32x4*)((const float*)dy + (size_t)sm * d))[i];
+                } else {
+                    const bf16x4 t = ((const bf16x4*)((const bf16*)dy + (size_t)sm * d))[i];
+                    r.dy[j] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                }
+                r.x[j] = ((const f32x4*)(x + (size_t)m * d))[i];
+                r.dr[j] = dres ? ((const f32x4*)(dres + (size_t)m * d))[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    Row cur, nxt;
+    int m = r0 + wave;
+    if (m < r1) fetch(m, cur);
+    for (; m < r1; m += 4) {
+        if (m + 4 < r1) fetch(m + 4, nxt);
+        const float mu = cur.mu, rs = cur.rs;
         f32x4 g[VPL], xh[VPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
-                f32x4 dyv;
-                if constexpr (DY_F32) {
-                    dyv = ((const f32x4*)((const float*)dy + (size_t)sm * d))[i];
-                } else {
-                    const bf16x4 t = ((const bf16x4*)((const bf16*)dy + (size_t)sm * d))[i];
-                    dyv = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-                }
-                const f32x4 xv = ((const f32x4*)(x + (size_t)m * d))[i];
+                const f32x4 dyv = cur.dy[j], xv = cur.x[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     xh[j][k] = (xv[k] - mu) * rs;
@@ -121,10 +143,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 f32x4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = rs * (g[j][k] - c1 - xh[j][k] * c2);
-                if (dres) o += ((const f32x4*)(dres + (size_t)m * d))[i];
+                if (dres) o += cur.dr[j];
                 ((f32x4*)(dx + (size_t)m * d))[i] = o;
             }
         }
+        cur = nxt;
     }
     // cross-wave reduction of the column sums, then one atomic per column per block
 #pragma unroll
