@@ -235,12 +235,18 @@ def main():
                     'flops_per_launch': round(flops / n)}
         if roof is not None:        # HBM bytes per launch from the committed PMC passes of this same command
             try:
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['kernels']
+                import re
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_f_traffic.json')))['kernels']
+                m = re.match(r'(gemm_[nt]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', roof['kernel'])
+                epi = {'bias': 0, 'bias_gelu': 1, 'resid': 2, 'dgelu': 3, 'f32': 4, 'dual': 5, 'argmax': 6}
+                pat = f'{m.group(1)}IDF16bLi{m.group(3)}ELi{m.group(4)}ELi\\dELi\\dE'
+                if m.group(2):
+                    pat += f'Li{epi[m.group(2)]}E'
                 for k, v in tr.items():
-                    if roof['kernel'].split('<')[0] in k and (roof['kernel'].startswith('gemm_tn') or 'Li' in k):
+                    if re.search(pat, k):
                         roof['traffic'] = round(v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
                         break
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, AttributeError):
                 pass
         out = {
             'metric': 'image-text pairs/sec fwd+bwd, VLMo-Base, 1/2/4/8 MI355X; % bf16 MFMA roofline',
