@@ -88,6 +88,11 @@ def cpu_baseline(preset, B=8, reps=3):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: libraries that print to file descriptor 1 while they initialise
+    # (RCCL's version banner at communicator creation) are sent to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
@@ -270,6 +275,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.preset)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if reducer is not None:
         reducer.close()
