@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (pairs)')
     ap.add_argument('--preset', default='base')
     ap.add_argument('--tile', type=int, default=None)
+    ap.add_argument('--merge-passes', action='store_true',
+                    help='full objective only: batch the backbone passes by mode (V / L / VL): 3 passes instead of 7')
     ap.add_argument('--optimizer', action='store_true',
                     help='also run the fused AdamW step with global-norm clip 5.0 (conf/train/pretrain_mum.yaml:28-36,54,75-80) '
                          'inside the timed step; the headline metric is forward+backward only, so this is off by default')
@@ -136,6 +138,7 @@ def main():
         from exploremultimodal_amd.build import build_model as build_module
         cfg = synth.make_config(args.preset, loss_names=['mlm', 'mim', 'itc', 'itm'], drop_rate=drop,
                                 attn_drop_rate=drop, drop_path_rate=drop)
+        cfg.train.merge_passes = args.merge_passes
         torch.manual_seed(0)
         model, mc = build_module(cfg).to(dev), cfg.model
     else:
@@ -260,7 +263,8 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': (f'VLMo-{args.preset} VL forward_features fwd+bwd' if args.objective == 'vl' else
                                     f'VLMo-{args.preset} VlmoModule.forward [mlm,mim,itc,itm] + in-loop dVAE, fwd+bwd'
-                                    + (', ZeRO-2 grad partition' if args.zero2 else '')) +
+                                    + (', ZeRO-2 grad partition' if args.zero2 else '')
+                                    + (', passes merged by mode' if args.merge_passes else '')) +
                                    f', per-GPU batch {B} synthetic 224x224 image + {mc.max_text_len}-token text '
                                    f'pairs, dropout/drop-path {0.0 if args.no_dropout else 0.1}'
                                    + (', + fused AdamW step with clip 5.0' if args.optimizer else ''),

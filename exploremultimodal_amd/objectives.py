@@ -26,7 +26,9 @@ def compute_accuracy(logits, target):
 def compute_mlm(model, batch):
     """objectives.py:40-78."""
     has_img = any(['image' in k for k in batch.keys()])
-    infer = model.infer(batch, infer_mode='img-txt' if has_img else 'txt_only', mask_txt=True, mask_img=False)
+    infer = batch.get('_mlm_infer')
+    if infer is None:
+        infer = model.infer(batch, infer_mode='img-txt' if has_img else 'txt_only', mask_txt=True, mask_img=False)
     txt_feats = infer['txt_feats']
     mlm_labels = infer['txt_labels']
     mask = (mlm_labels != -100).unsqueeze(-1).expand_as(txt_feats)
@@ -51,8 +53,8 @@ def compute_itc(model, batch):
     temp = model.itc_temp.exp()
     if model.config.train.global_reduce or model.transformer_m is not None:
         raise NotImplementedError('global_reduce / momentum ITC branches are out of scope (SURVEY.md 8f)')
-    img_infer = model.infer(batch, infer_mode='img_only')
-    txt_infer = model.infer(batch, infer_mode='txt_only')
+    img_infer = batch.get('_itc_img_infer') or model.infer(batch, infer_mode='img_only')
+    txt_infer = batch.get('_itc_txt_infer') or model.infer(batch, infer_mode='txt_only')
     i_feat = model.itc_head(img_infer['co_feats'][:, 0], 'v')
     t_feat = model.itc_head(txt_infer['co_feats'][:, 0], 'l')
     bs = i_feat.size(0)
@@ -69,31 +71,44 @@ def compute_itc(model, batch):
             'itc_t2i_mean_acc': itc_t2i_mean_acc, 'itc_t2i_count': itc_t2i_count}
 
 
-def compute_itm(model, batch, sim_dict=None):
-    """objectives.py:239-314."""
-    txt_ids, txt_mask, img = batch['text_ids'], batch['text_mask'], batch['image']
+def sample_itm_negatives(batch, sim_dict=None):
+    """Hard-negative indices of compute_itm (objectives.py:251-275) -> (img_neg_idx, txt_neg_idx), both [B]."""
+    img = batch['image']
     bs = img.size(0)
-    output_pos = model.infer(batch, infer_mode='img-txt')
     with torch.no_grad():
         if batch.get('itm_neg_idx') is not None:
-            img_neg_idx, txt_neg_idx = batch['itm_neg_idx']
+            return batch['itm_neg_idx']
+        if sim_dict is not None:
+            weights_i2t = F.softmax(sim_dict['sim_i2t'][:, :bs].float(), dim=1) + 1e-5
+            weights_t2i = F.softmax(sim_dict['sim_t2i'][:, :bs].float(), dim=1) + 1e-5
         else:
-            if sim_dict is not None:
-                weights_i2t = F.softmax(sim_dict['sim_i2t'][:, :bs].float(), dim=1) + 1e-5
-                weights_t2i = F.softmax(sim_dict['sim_t2i'][:, :bs].float(), dim=1) + 1e-5
-            else:
-                weights_i2t = F.softmax(torch.randn([bs, bs], device=img.device), dim=1) + 1e-5
-                weights_t2i = F.softmax(torch.randn([bs, bs], device=img.device), dim=1) + 1e-5
-            weights_i2t.fill_diagonal_(0)
-            weights_t2i.fill_diagonal_(0)
-            img_neg_idx = torch.multinomial(weights_t2i, 1).squeeze(1)     # one draw per row, no host sync
-            txt_neg_idx = torch.multinomial(weights_i2t, 1).squeeze(1)
-    img_neg = img[img_neg_idx]
-    txt_ids_all = torch.cat([txt_ids, txt_ids[txt_neg_idx]], dim=0)
-    txt_mask_all = torch.cat([txt_mask, txt_mask[txt_neg_idx]], dim=0)
-    img_all = torch.cat([img_neg, img], dim=0)
-    itm_neg_batch = {'text_ids': txt_ids_all, 'text_mask': txt_mask_all, 'image': img_all}
-    output_neg = model.infer(itm_neg_batch, infer_mode='img-txt')
+            weights_i2t = F.softmax(torch.randn([bs, bs], device=img.device), dim=1) + 1e-5
+            weights_t2i = F.softmax(torch.randn([bs, bs], device=img.device), dim=1) + 1e-5
+        weights_i2t.fill_diagonal_(0)
+        weights_t2i.fill_diagonal_(0)
+        img_neg_idx = torch.multinomial(weights_t2i, 1).squeeze(1)     # one draw per row, no host sync
+        txt_neg_idx = torch.multinomial(weights_i2t, 1).squeeze(1)
+    return img_neg_idx, txt_neg_idx
+
+
+def itm_negative_batch(batch, img_neg_idx, txt_neg_idx):
+    """The 2B-pair negative batch of compute_itm (objectives.py:277-293): (negative image, text), (image, negative text)."""
+    txt_ids, txt_mask, img = batch['text_ids'], batch['text_mask'], batch['image']
+    return {'text_ids': torch.cat([txt_ids, txt_ids[txt_neg_idx]], dim=0),
+            'text_mask': torch.cat([txt_mask, txt_mask[txt_neg_idx]], dim=0),
+            'image': torch.cat([img[img_neg_idx], img], dim=0)}
+
+
+def compute_itm(model, batch, sim_dict=None):
+    """objectives.py:239-314.  ``batch['_itm_infer'] = (output_pos, output_neg)`` (set by the merged-pass forward of
+    VlmoModule) supplies the two backbone results instead of running them here."""
+    bs = batch['image'].size(0)
+    if batch.get('_itm_infer') is not None:
+        output_pos, output_neg = batch['_itm_infer']
+    else:
+        output_pos = model.infer(batch, infer_mode='img-txt')
+        img_neg_idx, txt_neg_idx = sample_itm_negatives(batch, sim_dict)
+        output_neg = model.infer(itm_negative_batch(batch, img_neg_idx, txt_neg_idx), infer_mode='img-txt')
     cls_feat = torch.cat([output_pos['cls_feats'], output_neg['cls_feats']], dim=0)
     itm_logits = model.itm_head(cls_feat)
     itm_labels = torch.cat([torch.ones(1 * bs, dtype=torch.long, device=itm_logits.device),
@@ -112,7 +127,9 @@ def compute_mim(module, batch):
         bool_masked_pos = batch['image_bool_masked_pos']
         mim_labels = input_ids[bool_masked_pos]
     pos = module.config.train.mim_head_pos
-    if pos in ['img']:
+    if batch.get('_mim_infer') is not None:
+        infer = batch['_mim_infer']
+    elif pos in ['img']:
         infer = module.infer(batch, infer_mode='img_only', mask_txt=False, mask_img=True)
     elif pos in ['mum']:
         infer = module.infer(batch, infer_mode='img-txt', mask_txt=False, mask_img=True)

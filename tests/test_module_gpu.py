@@ -96,3 +96,33 @@ def test_module_training_step_runs():
     total.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert ret['itm_logits'].shape == (18, 2)
+
+
+def test_merged_passes_equal_pass_by_pass(golden_dir):
+    """config.train.merge_passes: V / L / VL passes batched by mode give the same outputs as the reference's
+    pass-by-pass order (rows are independent; forward values bit-identical, gradients to summation order)."""
+    g = np.load(os.path.join(golden_dir, 'module_mini.npz'))
+    B = int(g['meta.B'])
+    outs = []
+    for merged in (False, True):
+        model, cfg = _build()
+        cfg.train.merge_passes = merged
+        batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, B, seed=1234).items()}
+        batch['itm_neg_idx'] = (torch.from_numpy(g['itm_img_neg_idx']).to(DEV), torch.from_numpy(g['itm_txt_neg_idx']).to(DEV))
+        ret = model(batch)
+        total = sum(v for k, v in ret.items() if 'task_loss' in k)
+        total.backward()
+        outs.append((ret, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (r0, g0), (r1, g1) = outs
+    assert set(r0) == set(r1)
+    for k in r0:
+        if torch.is_tensor(r0[k]):
+            a, b = r0[k].detach().float(), r1[k].detach().float()
+            assert a.shape == b.shape, k
+            assert torch.allclose(a, b, rtol=0, atol=1e-6), (k, (a - b).abs().max().item())
+        else:
+            assert r0[k] == r1[k], k
+    assert set(g0) == set(g1)
+    for k in g0:
+        denom = g0[k].norm().item() + 1e-12
+        assert (g0[k] - g1[k]).norm().item() / denom <= 2e-2, (k, (g0[k] - g1[k]).norm().item() / denom)
