@@ -20,6 +20,7 @@ GRAD_SINK = None         # set by dp.GradReducer: block gradients are accumulate
 import os as _os
 OVERLAP_WGRAD = _os.environ.get('VLMO_OVERLAP_WGRAD', '1') != '0'   # weight-gradient GEMMs + bias column sums on a side stream
 SIDE_MODE = _os.environ.get('VLMO_SIDE_STREAM', 'low')
+MERGE_SEPARATE_ATTENTION = _os.environ.get('VLMO_MERGE_ATTN', '1') != '0'
 DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
 
@@ -83,6 +84,9 @@ class _PlanStatic:
         self.seg_txt = seg(ar * T, tl, z, z) if T else None
         self.seg_img = seg(nt + ar * P, pl, z, z) if P else None
         self.seg_vl = seg(ar * T, tl, nt + ar * P, pl) if (T and P) else None
+        # below the fusion layer text and image sequences attend separately but in ONE launch (longest first:
+        # the workgroups of the short text sequences fill the tail of the image ones)
+        self.seg_sep = torch.cat([self.seg_img, self.seg_txt]).contiguous() if (T and P) else None
         # packed row -> row of the [B, T+P, d] output (text first, vlmo.py:406)
         N = T + P
         rm_t = (torch.arange(B).view(B, 1) * N + torch.arange(T).view(1, T)).reshape(-1)
@@ -103,7 +107,7 @@ class Plan:
         self.M = self.nt + self.ni
         self.device = device
         st = _PlanStatic.get(B, T, P, device)
-        self.seg_txt, self.seg_img, self.seg_vl = st.seg_txt, st.seg_img, st.seg_vl
+        self.seg_txt, self.seg_img, self.seg_vl, self.seg_sep = st.seg_txt, st.seg_img, st.seg_vl, st.seg_sep
         self.rowmap, self.row_group = st.rowmap, st.row_group
         # key-padding mask over packed rows (vlmo.py:89-91); None = all valid
         parts = []
@@ -118,6 +122,8 @@ class Plan:
     def attn_launches(self, fused):
         if fused and self.seg_vl is not None:
             return [(self.seg_vl, self.B, self.T + self.P)]
+        if self.seg_sep is not None and MERGE_SEPARATE_ATTENTION:
+            return [(self.seg_sep, 2 * self.B, max(self.T, self.P))]
         out = []
         if self.seg_txt is not None:
             out.append((self.seg_txt, self.B, self.T))
