@@ -71,10 +71,19 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
         TRY(vlmo_gemm_nt(VLMO_EPI_RESID, VLMO_BF16, b->tile, b->ctx, d, b->proj_w, d, M, d, d, &e, st));
     }
     TRY(vlmo_ln_fwd(b->x1, b->n2w, b->n2b, b->y2, 0, b->mean2, b->rstd2, nullptr, M, d, b->eps, st));
+    // expert FFNs: all experts of the block in ONE grouped launch per linear (row ranges, weights and biases
+    // differ per expert; a launch costs at least one tile time, so per-expert launches of the 4 096 text rows
+    // and the 12 608 image rows would cost two)
+    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 4, "vlmo_block_fwd: 1..4 experts per block");
+    const void *a1[4], *w1[4], *a2[4], *w2[4];
+    int32_t rows[4];
+    VlmoEpilogue e1[4], e2[4];
     for (int x = 0; x < b->n_experts; ++x) {
         const size_t r0 = b->exp_row0[x];
-        const int n = b->exp_rows[x];
-        VlmoEpilogue e = epi();
+        rows[x] = b->exp_rows[x];
+        a1[x] = bp(b->y2, r0, d, 2);
+        w1[x] = b->w1[x];
+        VlmoEpilogue& e = e1[x] = epi();
         e.out = bp(b->u, r0, hid, 2);
         e.out2 = bp(b->h, r0, hid, 2);
         e.ldo = e.ld2 = hid;
@@ -82,8 +91,9 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
-        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS_GELU, VLMO_BF16, b->tile, bp(b->y2, r0, d, 2), d, b->w1[x], d, n, hid, d, &e, st));
-        VlmoEpilogue f = epi();
+        a2[x] = bp(b->h, r0, hid, 2);
+        w2[x] = b->w2[x];
+        VlmoEpilogue& f = e2[x] = epi();
         f.out = bp(b->x2, r0, d, 4);
         f.ldo = d;
         f.out2 = b->need_bwd ? bp(b->zd2, r0, d, 2) : nullptr;
@@ -96,8 +106,9 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
         f.drop_thresh = b->drop_thresh;
         f.inv_keep = b->inv_keep;
         f.seed = b->seed + 21 + 2 * x;
-        TRY(vlmo_gemm_nt(VLMO_EPI_RESID, VLMO_BF16, b->tile, bp(b->h, r0, hid, 2), hid, b->w2[x], hid, n, d, hid, &f, st));
     }
+    TRY(vlmo_gemm_nt_grouped(VLMO_EPI_BIAS_GELU, VLMO_BF16, b->tile, b->n_experts, a1, d, w1, d, rows, hid, d, e1, st));
+    TRY(vlmo_gemm_nt_grouped(VLMO_EPI_RESID, VLMO_BF16, b->tile, b->n_experts, a2, hid, w2, hid, rows, d, hid, e2, st));
     return 0;
 }
 
@@ -137,17 +148,24 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     auto ws_slot = [&](int k) { return defer ? (float*)((char*)b->ws_main + k * slot) : b->ws_main; };
     PartialReduce pend[6];
     auto arm = [&](int k) { vlmo_defer_reduce = defer ? &pend[k] : nullptr; };
-    // ---- FFN half
+    // ---- FFN half: per-expert residual-branch backward, then the two dgrad GEMMs of ALL experts as grouped
+    // launches on the main stream and every expert's weight gradients on the side stream
+    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 3, "vlmo_block_bwd: 1..3 experts per block");
+    const void *ag[4], *wg[4], *af[4], *wf[4];
+    int32_t rows[4];
+    VlmoEpilogue eg[4], ef[4];
     for (int x = 0; x < b->n_experts; ++x) {
         const size_t r0 = b->exp_row0[x];
-        const int n = b->exp_rows[x];
+        const int n = rows[x] = b->exp_rows[x];
         arm(2 + x);
         TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2,
                            b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr),
                            b->row_index ? b->row_index + r0 : nullptr, bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d, b->drop_thresh, b->inv_keep,
                            b->seed + 21 + 2 * x, ws_slot(2 + x), slot, st));
         vlmo_defer_reduce = nullptr;
-        VlmoEpilogue e = epi();
+        ag[x] = bp(b->dz2, r0, d, 2);
+        wg[x] = b->w2T[x];
+        VlmoEpilogue& e = eg[x] = epi();
         e.out = bp(b->du, r0, hid, 2);
         e.ldo = hid;
         e.aux = bp(b->u, r0, hid, 2);
@@ -155,17 +173,23 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
-        TRY(vlmo_gemm_nt(VLMO_EPI_DGELU, VLMO_BF16, b->tile, bp(b->dz2, r0, d, 2), d, b->w2T[x], d, n, hid, d, &e, st));
-        fork();
+        af[x] = bp(b->du, r0, hid, 2);
+        wf[x] = b->w1T[x];
+        VlmoEpilogue& f = ef[x] = epi();
+        f.out = bp(b->dy2, r0, d, 2);
+        f.ldo = d;
+    }
+    TRY(vlmo_gemm_nt_grouped(VLMO_EPI_DGELU, VLMO_BF16, b->tile, b->n_experts, ag, d, wg, d, rows, hid, d, eg, st));
+    fork();
+    for (int x = 0; x < b->n_experts; ++x) {
+        const size_t r0 = b->exp_row0[x];
+        const int n = b->exp_rows[x];
         TRY(reduce_partials(pend[2 + x], side));
         TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
         TRY(vlmo_colsum(VLMO_BF16, bp(b->du, r0, hid, 2), hid, b->db1[x], n, hid, ws_side, b->ws_bytes, side));
         TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
-        VlmoEpilogue f = epi();
-        f.out = bp(b->dy2, r0, d, 2);
-        f.ldo = d;
-        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, bp(b->du, r0, hid, 2), hid, b->w1T[x], hid, n, d, hid, &f, st));
     }
+    TRY(vlmo_gemm_nt_grouped(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->n_experts, af, hid, wf, hid, rows, d, hid, ef, st));
     arm(0);
     TRY(vlmo_ln_bwd(b->dy2, 0, nullptr, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, M, d,
                     ws_slot(0), slot, st));

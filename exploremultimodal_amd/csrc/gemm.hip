@@ -36,6 +36,16 @@ struct GemmNT {
     int group_m;     // L2 tile swizzle: row-tiles per group
 };
 
+// Up to 4 problems with the same N, K, leading dimensions and epilogue kind in ONE launch (the per-modality
+// expert FFNs below the fusion layer: different row ranges, weights, biases): group g owns the logical tiles
+// [t0[g], t0[g+1]).  A launch never takes less than one tile time, so two half-empty launches cost twice one.
+constexpr int MAX_GROUPS = 4;
+struct GemmNTGroups {
+    int ngroups;
+    int t0[MAX_GROUPS + 1];
+    GemmNT g[MAX_GROUPS];
+};
+
 // element address split into a wave-uniform 64-bit part and a per-lane 32-bit part
 struct RowAddr {
     size_t base;
@@ -161,7 +171,7 @@ template <int BK> __device__ __forceinline__ int nt_swz(int row) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK, int NSTG, bool PP = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGroups gp) {
     typedef typename Elem<T>::v8 v8;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -175,8 +185,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNT p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int lid_all = xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_GROUPS; ++q)
+        if (q < gp.ngroups && lid_all >= gp.t0[q]) gi = q;
+    gi = __builtin_amdgcn_readfirstlane(gi);
+    const GemmNT& p = gp.g[gi];
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = lid_all - gp.t0[gi];
     // grouped order: the ~64 tiles an XCD works on at once form a compact group_m x (64/group_m)
     // block, so their A row-panels AND B column-panels together fit the XCD's 4 MiB L2
     const int gm_ = p.group_m > 0 ? p.group_m : 1;
@@ -624,8 +641,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV = false, int BK = 64, int NSTG = 2, bool PP = false>
-int launch_nt(int epi, const GemmNT& p, hipStream_t st) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+int launch_nt(int epi, GemmNTGroups& p, hipStream_t st) {
+    int tiles = 0;
+    for (int q = 0; q < p.ngroups; ++q) {
+        p.t0[q] = tiles;
+        tiles += ((p.g[q].M + BM - 1) / BM) * ((p.g[q].N + BN - 1) / BN);
+    }
+    for (int q = p.ngroups; q <= MAX_GROUPS; ++q) p.t0[q] = tiles;
     constexpr int LDS = NSTG * (BM + BN) * BK * 2;
     dim3 grid(tiles), block(WM * WN * 64);
 #define VLMO_LAUNCH_EPI(E)                                                                     \
@@ -740,8 +762,8 @@ extern "C" int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* 
     return (int)g_prof.used;
 }
 
-extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
-                            int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream) {
+namespace {
+int check_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const VlmoEpilogue* e) {
     VLMO_CHECK_ARG(A && B && e, "vlmo_gemm_nt: null operand");
     VLMO_CHECK_ARG(M > 0 && N > 0 && K > 0, "vlmo_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
     VLMO_CHECK_ARG(K % 64 == 0, "vlmo_gemm_nt: K=%d must be a multiple of 64", K);
@@ -752,24 +774,66 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     VLMO_CHECK_ARG(epi != EPI_ARGMAX || e->ldo >= (N + 63) / 64, "vlmo_gemm_nt: argmax partial buffer too narrow");
     VLMO_CHECK_ARG(epi != EPI_RESID || e->resid, "vlmo_gemm_nt: residual epilogue needs resid");
     VLMO_CHECK_ARG(epi != EPI_DGELU || (e->aux && e->ld2 >= N), "vlmo_gemm_nt: dgelu epilogue needs aux");
+    return 0;
+}
+
+int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_nt: dtype must be bf16 or f16");
-    GemmNT p{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, 8};
-    if (const char* sv = getenv("VLMO_GROUP_M")) p.group_m = atoi(sv);
+    long Mtot = 0;
+    for (int q = 0; q < gp.ngroups; ++q) Mtot += gp.g[q].M;
+    const int N = gp.g[0].N, K = gp.g[0].K;
     if (tile < 0) {
         // measured on MI355X (tools/gemm_bench.py): deep reductions want the 256x256 ping-pong kernel (half
         // the staged bytes per flop, MFMA pipe and LDS port busy at the same time, one workgroup/CU);
         // shallow ones (K = d) are epilogue bound and want two 128x128 workgroups per CU so that one's
         // stores overlap the other's MFMAs
-        tile = (K >= 1536 && M >= 2048 && N >= 512) ? 3 : 0;
+        tile = (K >= 1536 && Mtot >= 2048 && N >= 512) ? 3 : 0;
     }
-    ProfScope prof(epi + (tile == 3 ? 8 : 0), 2.0 * M * N * K, stream);
+    ProfScope prof(epi + (tile == 3 ? 8 : 0), 2.0 * Mtot * N * K, stream);
     VLMO_CHECK_ARG(tile == 0 || tile == 3, "vlmo_gemm_nt: tile must be -1, 0 or 3 (got %d)", tile);
     if (dtype == VLMO_F16) {
-        if (tile == 3) return launch_nt<f16, 256, 256, 2, 4, false, 64, 2, true>(epi, p, stream);
-        return launch_nt<f16, 128, 128, 2, 2>(epi, p, stream);
+        if (tile == 3) return launch_nt<f16, 256, 256, 2, 4, false, 64, 2, true>(epi, gp, stream);
+        return launch_nt<f16, 128, 128, 2, 2>(epi, gp, stream);
     }
-    if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4, false, 64, 2, true>(epi, p, stream);
-    return launch_nt<bf16, 128, 128, 2, 2>(epi, p, stream);
+    if (tile == 3) return launch_nt<bf16, 256, 256, 2, 4, false, 64, 2, true>(epi, gp, stream);
+    return launch_nt<bf16, 128, 128, 2, 2>(epi, gp, stream);
+}
+
+int group_m_default() {
+    static const int v = [] {
+        const char* sv = getenv("VLMO_GROUP_M");
+        return sv ? atoi(sv) : 8;
+    }();
+    return v;
+}
+}  // namespace
+
+extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
+                            int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream) {
+    if (int rc = check_nt(epi, A, lda, B, ldb, M, N, K, e)) return rc;
+    GemmNTGroups gp{};
+    gp.ngroups = 1;
+    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_default()};
+    return run_nt(epi, dtype, tile, gp, stream);
+}
+
+extern "C" int vlmo_gemm_nt_grouped(int epi, int dtype, int tile, int ngroups, const void* const* A, int lda,
+                                    const void* const* B, int ldb, const int32_t* M, int N, int K,
+                                    const VlmoEpilogue* e, hipStream_t stream) {
+    VLMO_CHECK_ARG(ngroups >= 1 && ngroups <= MAX_GROUPS && A && B && M && e, "vlmo_gemm_nt_grouped: 1..%d groups", MAX_GROUPS);
+    VLMO_CHECK_ARG(epi != EPI_ARGMAX, "vlmo_gemm_nt_grouped: the arg-max epilogue is single-problem");
+#ifdef VLMO_NO_GROUPING      // measurement aid: one launch per group
+    for (int q = 0; q < ngroups; ++q)
+        if (int rc = vlmo_gemm_nt(epi, dtype, tile, A[q], lda, B[q], ldb, M[q], N, K, &e[q], stream)) return rc;
+    return 0;
+#endif
+    GemmNTGroups gp{};
+    gp.ngroups = ngroups;
+    for (int q = 0; q < ngroups; ++q) {
+        if (int rc = check_nt(epi, A[q], lda, B[q], ldb, M[q], N, K, &e[q])) return rc;
+        gp.g[q] = GemmNT{A[q], B[q], M[q], N, K, lda, ldb, e[q], 0, 0, 0, 0, nullptr, group_m_default()};
+    }
+    return run_nt(epi, dtype, tile, gp, stream);
 }
 
 namespace {
@@ -870,7 +934,9 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     VLMO_CHECK_ARG(e->out && e->ldo >= Cout, "vlmo_conv2d_nhwc: bad output");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_conv2d_nhwc: dtype must be bf16 or f16");
     const int K = kw * kw * Cin;
-    GemmNT p{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8};
+    GemmNTGroups p{};
+    p.ngroups = 1;
+    p.g[0] = GemmNT{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8};
     ProfScope prof(32 + epi, 2.0 * B * H * W * Cout * K, stream);
     if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);

@@ -84,6 +84,7 @@ _SIGS = {
     'vlmo_block_fwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_block_bwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_profile_start': [_i32],
+    'vlmo_gemm_nt_grouped': [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     'vlmo_mt_grad_norm': [ctypes.c_void_p, _f32, _f32, _vp, _vp, _vp],
     'vlmo_mt_adam': [ctypes.c_void_p, ctypes.c_void_p, _vp, _vp],
     'vlmo_side_stream_create': [_i32, ctypes.POINTER(ctypes.c_uint32), _i32, ctypes.POINTER(ctypes.c_void_p)],
@@ -175,6 +176,28 @@ def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=
                             _p(B), ldb if ldb is not None else B.stride(0), M, N, K,
                             ctypes.byref(e), _stream())
     _check(rc, 'vlmo_gemm_nt')
+
+
+def gemm_nt_grouped(epi, As, Bs, Ms, N, K, outs, *, per_group=None, tile=-1, **common):
+    """vlmo_gemm_nt_grouped: problems g = (As[g] [Ms[g], K], Bs[g] [N, K]) -> outs[g]; ``per_group[g]`` holds the
+    epilogue keywords of gemm_nt that differ per group (bias, out2, seed, ...), ``common`` the shared ones."""
+    n = len(As)
+    es = (Epilogue * n)()
+    for g in range(n):
+        kw = dict(common)
+        kw.update((per_group or [{}] * n)[g])
+        out, out2, aux = outs[g], kw.get('out2'), kw.get('aux')
+        drop = kw.get('drop', (0, 1.0))
+        es[g] = Epilogue(_p(out), _p(out2), _p(kw.get('bias')), _p(kw.get('gamma')), _p(kw.get('resid')),
+                         _p(kw.get('row_scale')), _p(kw.get('row_index')), _p(aux), out.stride(0),
+                         out2.stride(0) if out2 is not None else (aux.stride(0) if aux is not None else 0),
+                         int(kw.get('relu', False)), drop[0], drop[1], kw.get('beta', 0.0),
+                         kw.get('seed', 0) & 0xFFFFFFFFFFFFFFFF)
+    pa = (ctypes.c_void_p * n)(*[_p(a) for a in As])
+    pb = (ctypes.c_void_p * n)(*[_p(b) for b in Bs])
+    ms = (ctypes.c_int32 * n)(*Ms)
+    rc = lib().vlmo_gemm_nt_grouped(epi, _dt(As[0]), tile, n, pa, As[0].stride(0), pb, Bs[0].stride(0), ms, N, K, es, _stream())
+    _check(rc, 'vlmo_gemm_nt_grouped')
 
 
 _WS_TN = {}

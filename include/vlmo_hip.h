@@ -75,6 +75,14 @@ int vlmo_abi_version(void);
  * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */
 int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
                  int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream);
+/* 1..4 problems C_g[M_g,N] = A_g[M_g,K] . B_g[N,K]^T with the same N, K, leading dimensions and epilogue kind
+ * in ONE launch: the per-modality expert FFNs of a Block below the fusion layer (mlp['l'] on the text rows,
+ * mlp['v'] on the image rows: vlmo.py:141-157, 195-196).  e[g] is group g's epilogue (its own outputs, bias,
+ * dropout seed).  A launch takes at least one tile time however few tiles it has, so two half-empty launches
+ * cost twice one. */
+int vlmo_gemm_nt_grouped(int epi, int dtype, int tile, int ngroups, const void* const* A, int lda,
+                         const void* const* B, int ldb, const int32_t* M, int N, int K,
+                         const VlmoEpilogue* e, hipStream_t stream);
 
 /* C[N1,N2] += alpha * A[M,N1]^T . B[M,N2]  (weight gradients of the linears above, i.e. autograd of
  * vlmo.py:76-78,96,195-196).  The token dimension is split over workgroups; partial products go through

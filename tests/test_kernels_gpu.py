@@ -334,3 +334,40 @@ def test_embed_txt_fwd_bwd():
     hip.embed_txt_bwd(dx, ids, xhat, rstd, lw, outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], B, T, d)
     for got, leaf, name in zip(outs, L, ('dword', 'dpos', 'dbtype0', 'dlnw', 'dlnb', 'dtype0')):
         _close(got, leaf.grad, 1e-3, 1e-3, name)
+
+
+@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('epi', ['bias_gelu', 'resid'])
+def test_gemm_nt_grouped_equals_separate_launches(tile, epi):
+    """vlmo_gemm_nt_grouped (the per-modality expert FFNs in one launch) is bit-identical to one launch per
+    group, including the dropout streams (per-group seed, group-local element index); ragged group sizes."""
+    g = torch.Generator().manual_seed(7)
+    Ms, N, K = [300, 1000, 129], 384, 128
+    As = [torch.randn(m, K, generator=g).to(DEV).bfloat16() for m in Ms]
+    Bs = [(torch.randn(N, K, generator=g) * 0.1).to(DEV).bfloat16() for _ in Ms]
+    biases = [torch.randn(N, generator=g).to(DEV) for _ in Ms]
+    drop = hip.drop_params(0.1, True)
+    if epi == 'bias_gelu':
+        code, odt = hip.EPI_BIAS_GELU, torch.bfloat16
+        mk = lambda i, m: dict(bias=biases[i], out2=torch.empty(m, N, device=DEV, dtype=torch.bfloat16), seed=100 + i)
+        common = dict(drop=drop)
+    else:
+        code, odt = hip.EPI_RESID, torch.float32
+        gamma = torch.rand(N, generator=g).to(DEV)
+        resids = [torch.randn(m, N, generator=g).to(DEV) for m in Ms]
+        mk = lambda i, m: dict(bias=biases[i], resid=resids[i], out2=torch.empty(m, N, device=DEV, dtype=torch.bfloat16),
+                               seed=200 + i)
+        common = dict(drop=drop, gamma=gamma)
+    sep, sep_kw = [], []
+    for i, m in enumerate(Ms):
+        out = torch.empty(m, N, device=DEV, dtype=odt)
+        kw = mk(i, m)
+        hip.gemm_nt(code, As[i], Bs[i], m, N, K, out, tile=tile, **common, **kw)
+        sep.append(out)
+        sep_kw.append(kw)
+    outs = [torch.full((m, N), float('nan'), device=DEV, dtype=odt) for m in Ms]
+    grp_kw = [mk(i, m) for i, m in enumerate(Ms)]
+    hip.gemm_nt_grouped(code, As, Bs, Ms, N, K, outs, per_group=grp_kw, tile=tile, **common)
+    for i in range(len(Ms)):
+        assert torch.equal(outs[i], sep[i]), i
+        assert torch.equal(grp_kw[i]['out2'], sep_kw[i]['out2']), i
