@@ -134,10 +134,14 @@ class Block(nn.Module):
             ps += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
         return ps
 
-    def run(self, x, plan, routes, ranges, fused, shadows, seed):
-        """x: packed fp32 [M, d]; routes/ranges: experts and their row ranges."""
+    def run(self, x, plan, routes, ranges, fused, shadows, seed, drop_scales=None):
+        """x: packed fp32 [M, d]; routes/ranges: experts and their row ranges; drop_scales: this block's
+        drop-path scales [branch, stream, B] when the caller drew them for all blocks at once."""
         rs1 = rs2 = None
-        if self.training and self.drop_path_rate > 0.0:
+        if drop_scales is not None:
+            if self.drop_path_rate > 0.0:
+                rs1, rs2 = drop_scales[0].reshape(-1), drop_scales[1].reshape(-1)
+        elif self.training and self.drop_path_rate > 0.0:
             # timm DropPath: per-sample Bernoulli(keep)/keep, one draw per residual branch.  Below the fusion
             # layer the reference calls the block once per modality (vlmo.py:402-404), so the text and image
             # streams of a sample draw independently; above it the fused sequence shares one draw.
@@ -161,6 +165,18 @@ class Block(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0
         out = self.run(x.reshape(B * N, d).float().contiguous(), plan, [route], [(0, B * N)], False, shadows, seed)
         return out.view(B, N, d), None
+
+
+_CONSTS = {}
+
+
+def _const_to(t, device):
+    """Small host constant on the device, uploaded once per (values, device)."""
+    key = (tuple(t.reshape(-1).tolist()), tuple(t.shape), str(device))
+    v = _CONSTS.get(key)
+    if v is None:
+        v = _CONSTS[key] = t.to(device)
+    return v
 
 
 class VLMO(nn.Module):
@@ -283,9 +299,24 @@ class VLMO(nn.Module):
         return dev
 
     def _run_blocks(self, x, plan, mode, fusion_layer, layers, seed):
-        for i in layers:
-            routes, ranges, fused = self._routes(i, mode, fusion_layer, plan)
-            x = self.blocks[i].run(x, plan, routes, ranges, fused, self._shadows, seed + 1000 * (i + 1))
+        layers = list(layers)
+        todo = [(i,) + tuple(self._routes(i, mode, fusion_layer, plan)) for i in layers]
+        # drop-path draws of ALL blocks in three tiny kernels instead of three per block (each one is a launch
+        # and a dependency bubble on the main stream): Bernoulli(keep_i) / keep_i, layout [block, branch, stream, B]
+        scales = None
+        rates = [self.blocks[i].drop_path_rate for i in layers]
+        if self.training and layers and max(rates) > 0.0:
+            keep = 1.0 - torch.tensor(rates, dtype=torch.float32).view(-1, 1, 1, 1)
+            share = torch.tensor([1.0 if (f or not (plan.T and plan.P)) else 0.0 for _, _, _, f in todo]).view(-1, 1, 1)
+            kd, sd = _const_to(keep, x.device), _const_to(share, x.device)
+            u = torch.rand((len(layers), 2, 2, plan.B), device=x.device)
+            first = 0 if plan.T else 1
+            # fused / single-stream blocks: both streams of a sample share the draw of the stream that exists
+            u = torch.where(sd.unsqueeze(-1) > 0, u[:, :, first:first + 1].expand_as(u), u)
+            scales = (u < kd).to(torch.float32) / kd
+        for n, (i, routes, ranges, fused) in enumerate(todo):
+            x = self.blocks[i].run(x, plan, routes, ranges, fused, self._shadows, seed + 1000 * (i + 1),
+                                   drop_scales=scales[n] if scales is not None else None)
         return x
 
     # ------------------------------------------------------------ reference API
