@@ -190,14 +190,12 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         TRY(vlmo_gemm_tn(VLMO_BF16, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     }
     TRY(vlmo_gemm_nt_grouped(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->n_experts, af, hid, wf, hid, rows, d, hid, ef, st));
+    // norm2 backward fused with the attention branch's residual backward (it consumes the dx1 this writes):
+    // four column partials (dn2w, dn2b, dgamma_1, dproj_b) in slots 0-1
     arm(0);
-    TRY(vlmo_ln_bwd(b->dy2, 0, nullptr, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, M, d,
-                    ws_slot(0), slot, st));
-    vlmo_defer_reduce = nullptr;
-    // ---- attention half
-    arm(1);
-    TRY(vlmo_resid_bwd(b->dx1, b->zd1, b->g1, b->rs1, b->row_index, b->dz1, b->dg1, b->dproj_b, M, d, b->drop_thresh, b->inv_keep,
-                       b->seed + 1, ws_slot(1), slot, st));
+    TRY(vlmo_ln_resid_bwd(b->dy2, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, b->zd1, b->g1,
+                          b->rs1, b->row_index, b->dz1, b->dg1, b->dproj_b, b->drop_thresh, b->inv_keep, b->seed + 1, M, d,
+                          ws_slot(0), 2 * slot, st));
     vlmo_defer_reduce = nullptr;
     {
         VlmoEpilogue e = epi();
@@ -212,7 +210,6 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
                           b->seed + 11 + a, st));
     fork();     // one fork for the whole attention half: the proj gradient waits for it too (the side stream has slack)
     TRY(reduce_partials(pend[0], side));
-    TRY(reduce_partials(pend[1], side));
     TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
     TRY(vlmo_colsum(VLMO_BF16, b->dqkv, 3 * d, b->dqkv_b, M, 3 * d, ws_side, b->ws_bytes, side));
     TRY(vlmo_gemm_tn(VLMO_BF16, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));

@@ -44,7 +44,8 @@ void vlmo_set_error(const char* fmt, ...);
 // outputs with ~8 atomics per address.  (One atomic per column per workgroup straight
 // into the output serialises ~1000 adders on each address: measured 7x slower.)
 #define VLMO_MAX_PARTIAL_BLOCKS 512
-int reduce_partials(const float* ws, int nblk, int ncols, float* out0, int n0, float* out1, hipStream_t stream);
+int reduce_partials(const float* ws, int nblk, int ncols, float* out0, int n0, float* out1, hipStream_t stream,
+                    float* out2 = nullptr, float* out3 = nullptr);
 // vlmo_block_bwd runs these tiny folds on its side stream (they only produce parameter gradients; on the
 // caller's stream each one is a launch + dependency bubble on the critical path): while `vlmo_defer_reduce`
 // points at a record, the NEXT reduce_partials() of this thread fills it instead of launching.
@@ -54,10 +55,12 @@ struct PartialReduce {
     float* out0 = nullptr;
     int n0 = 0;
     float* out1 = nullptr;
+    float* out2 = nullptr;
+    float* out3 = nullptr;
 };
 extern thread_local PartialReduce* vlmo_defer_reduce;
 inline int reduce_partials(const PartialReduce& r, hipStream_t stream) {
-    return r.ws ? reduce_partials(r.ws, r.nblk, r.ncols, r.out0, r.n0, r.out1, stream) : 0;
+    return r.ws ? reduce_partials(r.ws, r.nblk, r.ncols, r.out0, r.n0, r.out1, stream, r.out2, r.out3) : 0;
 }
 inline int64_t reduce_ws_need(int ncols) { return (int64_t)VLMO_MAX_PARTIAL_BLOCKS * ncols * 4; }
 

@@ -20,10 +20,11 @@ extern "C" int vlmo_abi_version(void) { return 1; }
 
 namespace {
 
-// out0[c] += sum_b ws[b][c] (c < n0) ; out1[c - n0] += ... (c >= n0).  block (64, 4), grid (ncols/64, S)
+// out_k[c - k*n0] += sum_b ws[b][c] for k = c / n0 (up to 4 outputs of n0 columns each).  block (64, 4), grid (ncols/64, S)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk, int ncols,
                                                               float* __restrict__ out0, int n0,
-                                                              float* __restrict__ out1, int rows_per_slice) {
+                                                              float* __restrict__ out1, int rows_per_slice,
+                                                              float* __restrict__ out2, float* __restrict__ out3) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + threadIdx.x;
     const int r0 = blockIdx.y * rows_per_slice, r1 = min(nblk, r0 + rows_per_slice);
@@ -34,8 +35,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     __syncthreads();
     if (threadIdx.y == 0 && c < ncols) {
         const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        float* o = c < n0 ? (out0 ? out0 + c : nullptr) : (out1 ? out1 + (c - n0) : nullptr);
-        if (o) atomicAdd(o, t);
+        const int k = c / n0;
+        float* base = k == 0 ? out0 : (k == 1 ? out1 : (k == 2 ? out2 : out3));
+        if (base) atomicAdd(base + (c - k * n0), t);
     }
 }
 
@@ -385,18 +387,20 @@ __global__ __launch_bounds__(256) void embed_txt_bwd_kernel(const float* __restr
 
 thread_local PartialReduce* vlmo_defer_reduce = nullptr;
 
-int reduce_partials(const float* ws, int nblk, int ncols, float* out0, int n0, float* out1, hipStream_t stream) {
+int reduce_partials(const float* ws, int nblk, int ncols, float* out0, int n0, float* out1, hipStream_t stream,
+                    float* out2, float* out3) {
     if (vlmo_defer_reduce) {
         PartialReduce* r = vlmo_defer_reduce;
         vlmo_defer_reduce = nullptr;
         r->ws = ws, r->nblk = nblk, r->ncols = ncols, r->out0 = out0, r->n0 = n0, r->out1 = out1;
+        r->out2 = out2, r->out3 = out3;
         return 0;
     }
     int slices = nblk >= 64 ? 8 : 1;
     const int rps = (nblk + slices - 1) / slices;
     slices = (nblk + rps - 1) / rps;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncols + 63) / 64, slices), dim3(64, 4), 0, stream, ws, nblk, ncols,
-                       out0, n0, out1, rps);
+                       out0, n0, out1, rps, out2, out3);
     VLMO_CHECK_LAUNCH("reduce_partials");
     return 0;
 }

@@ -63,22 +63,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-template <int VPL, bool DY_F32>
+// residual branch fed by the LayerNorm's input gradient (fused form): z = drop(branch) is what forward added as
+// x + gamma * rs * z, so dz = mask * dx * gamma * rs, dgamma = sum dx * rs * z, dbias = sum dz  (resid_bwd_kernel)
+struct ResidArgs {
+    const bf16* zd;
+    const float* gamma;
+    const float* row_scale;
+    const int32_t* row_index;
+    bf16* dz;
+    uint32_t thresh;
+    float inv_keep;
+    uint64_t seed;
+};
+
+template <int VPL, bool DY_F32, bool RESID>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const int32_t* __restrict__ rowmap,
                                                      const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
-                                                     float* __restrict__ ws, int M, int d, int rows_per_block) {
-    __shared__ float red[4][2][VPL * 256];
+                                                     float* __restrict__ ws, int M, int d, int rows_per_block,
+                                                     const ResidArgs ra) {
+    constexpr int NCOL = RESID ? 4 : 2;      // column partials per block: dw, db (, dgamma, dbias)
+    __shared__ float red[4][NCOL][VPL * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    f32x4 aw[VPL], ab[VPL], ww[VPL];
+    f32x4 aw[VPL], ab[VPL], ww[VPL], ag[VPL], az[VPL], gg[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         aw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ab[j] = aw[j];
+        ab[j] = ag[j] = az[j] = aw[j];
         const int i = lane + 64 * j;
         ww[j] = (i < nv) ? ((const f32x4*)w)[i] : aw[j];
+        gg[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (RESID && ra.gamma && i < nv) gg[j] = ((const f32x4*)ra.gamma)[i];
     }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
@@ -87,12 +104,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     // waves per SIMD, so its speed is (bytes in flight per wave) / latency, not occupancy.
     struct Row {
         f32x4 dy[VPL], x[VPL], dr[VPL];
-        float mu, rs;
+        bf16x4 z[VPL];
+        float mu, rs, scale;
     };
     auto fetch = [&](int m, Row& r) {
         const int sm = rowmap ? rowmap[m] : m;
         r.mu = mean[m];
         r.rs = rstd[m];
+        if constexpr (RESID) r.scale = ra.row_scale ? ra.row_scale[ra.row_index ? ra.row_index[m] : m] : 1.f;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const int i = lane + 64 * j;
@@ -105,6 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 }
                 r.x[j] = ((const f32x4*)(x + (size_t)m * d))[i];
                 r.dr[j] = dres ? ((const f32x4*)(dres + (size_t)m * d))[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (RESID) r.z[j] = ((const bf16x4*)(ra.zd + (size_t)m * d))[i];
             }
         }
     };
@@ -145,6 +165,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 for (int k = 0; k < 4; ++k) o[k] = rs * (g[j][k] - c1 - xh[j][k] * c2);
                 if (dres) o += cur.dr[j];
                 ((f32x4*)(dx + (size_t)m * d))[i] = o;
+                if constexpr (RESID) {
+                    const f32x4 orr = o * cur.scale;
+                    f32x4 v = o * gg[j] * cur.scale;      // same association as resid_bwd_kernel: (dx * gamma) * rs
+                    if (ra.thresh) {
+                        const uint64_t bits = drop_bits4(ra.seed, ((uint64_t)m * d + 4 * i) >> 2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = drop_keep(bits, k, ra.thresh) ? v[k] * ra.inv_keep : 0.f;
+                    }
+                    const bf16x4 vb = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    ((bf16x4*)(ra.dz + (size_t)m * d))[i] = vb;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ag[j][k] += orr[k] * (float)cur.z[j][k];
+                        az[j][k] += v[k];
+                    }
+                }
             }
         }
         cur = nxt;
@@ -156,16 +192,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int k = 0; k < 4; ++k) {
             red[wave][0][(j * 64 + lane) * 4 + k] = aw[j][k];
             red[wave][1][(j * 64 + lane) * 4 + k] = ab[j][k];
+            if constexpr (RESID) {
+                red[wave][2][(j * 64 + lane) * 4 + k] = ag[j][k];
+                red[wave][3][(j * 64 + lane) * 4 + k] = az[j][k];
+            }
         }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
         // column c lives at vector i = c/4 -> (j = i/64, lane = i%64), slot k = c%4
         const int i = c >> 2, idx = ((i >> 6) * 64 + (i & 63)) * 4 + (c & 3);
-        const float sw = red[0][0][idx] + red[1][0][idx] + red[2][0][idx] + red[3][0][idx];
-        const float sb = red[0][1][idx] + red[1][1][idx] + red[2][1][idx] + red[3][1][idx];
         if (ws) {
-            ws[(size_t)blockIdx.x * 2 * d + c] = sw;
-            ws[(size_t)blockIdx.x * 2 * d + d + c] = sb;
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q)
+                ws[((size_t)blockIdx.x * NCOL + q) * d + c] = red[0][q][idx] + red[1][q][idx] + red[2][q][idx] + red[3][q][idx];
         }
     }
 }
@@ -194,25 +233,30 @@ extern "C" int vlmo_ln_fwd(const float* x, const float* w, const float* b, void*
     return 0;
 }
 
-extern "C" int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, const float* x, const float* w,
-                           const float* mean, const float* rstd, const float* dres, float* dx, float* dw, float* db,
-                           int M, int d, float* ws, int64_t ws_bytes, hipStream_t stream) {
+namespace {
+int ln_bwd_launch(const void* dy, int dy_f32, const int32_t* rowmap, const float* x, const float* w, const float* mean,
+                  const float* rstd, const float* dres, float* dx, float* dw, float* db, int M, int d, float* ws,
+                  int64_t ws_bytes, const ResidArgs* ra, float* dgamma, float* dbias, hipStream_t stream) {
     VLMO_CHECK_ARG(dy && x && w && mean && rstd && dx, "vlmo_ln_bwd: null pointer");
     VLMO_CHECK_ARG(M > 0 && d > 0 && d % 4 == 0 && d <= 1024, "vlmo_ln_bwd: need 0 < d <= 1024, d %% 4 == 0 (d=%d, M=%d)", d, M);
-    const bool need_w = dw || db;
-    VLMO_CHECK_ARG(!need_w || (ws && ws_bytes >= reduce_ws_need(2 * d)),
-                   "vlmo_ln_bwd: workspace too small (need %lld bytes)", (long long)reduce_ws_need(2 * d));
+    const int ncol = ra ? 4 : 2;
+    const bool need_w = dw || db || ra;
+    VLMO_CHECK_ARG(!need_w || (ws && ws_bytes >= reduce_ws_need(ncol * d)),
+                   "vlmo_ln_bwd: workspace too small (need %lld bytes)", (long long)reduce_ws_need(ncol * d));
     if (!need_w) ws = nullptr;
     const int vpl = (d / 4 + 63) / 64;
     int rpb = (M + VLMO_MAX_PARTIAL_BLOCKS - 1) / VLMO_MAX_PARTIAL_BLOCKS;
     rpb = ((rpb + 3) / 4) * 4;
     if (rpb < 8) rpb = 8;
     const int grid = (M + rpb - 1) / rpb;
+    const ResidArgs none{};
 #define LNB(V)                                                                                         \
-    if (dy_f32)                                                                                        \
-        hipLaunchKernelGGL((ln_bwd_kernel<V, true>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb); \
+    if (ra)                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<V, false, true>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb, *ra); \
+    else if (dy_f32)                                                                                   \
+        hipLaunchKernelGGL((ln_bwd_kernel<V, true, false>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb, none); \
     else                                                                                               \
-        hipLaunchKernelGGL((ln_bwd_kernel<V, false>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb);
+        hipLaunchKernelGGL((ln_bwd_kernel<V, false, false>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb, none);
     switch (vpl) {
         case 1: LNB(1) break;
         case 2: LNB(2) break;
@@ -221,6 +265,24 @@ extern "C" int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, co
     }
 #undef LNB
     VLMO_CHECK_LAUNCH("vlmo_ln_bwd");
-    if (need_w) return reduce_partials(ws, grid, 2 * d, dw, d, db, stream);
+    if (need_w) return reduce_partials(ws, grid, ncol * d, dw, d, db, stream, dgamma, dbias);
     return 0;
+}
+}  // namespace
+
+extern "C" int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, const float* x, const float* w,
+                           const float* mean, const float* rstd, const float* dres, float* dx, float* dw, float* db,
+                           int M, int d, float* ws, int64_t ws_bytes, hipStream_t stream) {
+    return ln_bwd_launch(dy, dy_f32, rowmap, x, w, mean, rstd, dres, dx, dw, db, M, d, ws, ws_bytes, nullptr, nullptr,
+                         nullptr, stream);
+}
+
+extern "C" int vlmo_ln_resid_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                                 const float* dres, float* dx, float* dw, float* db, const void* zd, const float* gamma,
+                                 const float* row_scale, const int32_t* row_index, void* dz, float* dgamma, float* dbias,
+                                 uint32_t drop_thresh, float inv_keep, uint64_t seed, int M, int d, float* ws,
+                                 int64_t ws_bytes, hipStream_t stream) {
+    VLMO_CHECK_ARG(zd && dz, "vlmo_ln_resid_bwd: null pointer");
+    const ResidArgs ra{(const bf16*)zd, gamma, row_scale, row_index, (bf16*)dz, drop_thresh, inv_keep, seed};
+    return ln_bwd_launch(dy, 0, nullptr, x, w, mean, rstd, dres, dx, dw, db, M, d, ws, ws_bytes, &ra, dgamma, dbias, stream);
 }

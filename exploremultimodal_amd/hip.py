@@ -62,6 +62,8 @@ _SIGS = {
     'vlmo_gemm_tn': [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp],
     'vlmo_ln_fwd': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
     'vlmo_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp],
+    'vlmo_ln_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _f32, _u64,
+                          _i32, _i32, _vp, _i64, _vp],
     'vlmo_attn_fwd': [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _f32,
                       _u64, _vp],
     'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f32,
@@ -232,6 +234,15 @@ def ln_bwd(dy, rowmap, x, w, mean, rstd, dres, dx, dw, db, M, d):
                            _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), M, d, _p(ws := workspace(x.device, 2 * d)),
                            ws.numel() * 4, _stream())
     _check(rc, 'vlmo_ln_bwd')
+
+
+def ln_resid_bwd(dy, x, w, mean, rstd, dres, dx, dw, db, zd, gamma, row_scale, row_index, dz, dgamma, dbias, M, d,
+                 drop=(0, 1.0), seed=0):
+    ws = workspace(x.device, 4 * d)
+    rc = lib().vlmo_ln_resid_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), _p(zd),
+                                 _p(gamma), _p(row_scale), _p(row_index), _p(dz), _p(dgamma), _p(dbias), drop[0], drop[1],
+                                 seed & 0xFFFFFFFFFFFFFFFF, M, d, _p(ws), ws.numel() * 4, _stream())
+    _check(rc, 'vlmo_ln_resid_bwd')
 
 
 def attn_fwd(qkv, seg, nseq, keymask, ctx, lse, heads, d, max_len, scale, drop=(0, 1.0), seed=0):

@@ -108,6 +108,16 @@ int vlmo_ln_bwd(const void* dy, int dy_f32, const int32_t* rowmap, const float* 
                 const float* mean, const float* rstd, const float* dres, float* dx, float* dw,
                 float* db, int M, int d, float* ws, int64_t ws_bytes, hipStream_t stream);
 
+/* vlmo_ln_bwd (dy bf16, no row map) fused with the vlmo_resid_bwd of the residual branch that the LayerNorm's
+ * input gradient feeds next (Block backward: norm2, then the attention branch x1 = x + gamma_1 * rs * zd):
+ * dz = dropout_mask * dx * gamma * rs, dgamma += sum dx * rs * zd, dbias += sum dz, where dx is the value this
+ * call writes.  Saves re-reading dx (fp32 [M, d]) and one launch.  ws: vlmo_reduce_ws_bytes(4 * d). */
+int vlmo_ln_resid_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                      const float* dres, float* dx, float* dw, float* db, const void* zd, const float* gamma,
+                      const float* row_scale, const int32_t* row_index, void* dz, float* dgamma, float* dbias,
+                      uint32_t drop_thresh, float inv_keep, uint64_t seed, int M, int d, float* ws,
+                      int64_t ws_bytes, hipStream_t stream);
+
 /* Fused softmax attention over packed rows (vlmo.py:79-95).
  * qkv [M, 3*d] (q | k | v, head-major inside each third), ctx [M, d].
  * seg[s] = {rowA, lenA, rowB, lenB}: sequence s = rows [rowA,rowA+lenA) ++ [rowB,rowB+lenB).

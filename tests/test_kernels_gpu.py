@@ -371,3 +371,31 @@ def test_gemm_nt_grouped_equals_separate_launches(tile, epi):
     for i in range(len(Ms)):
         assert torch.equal(outs[i], sep[i]), i
         assert torch.equal(grp_kw[i]['out2'], sep_kw[i]['out2']), i
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.1])
+def test_ln_resid_bwd_equals_ln_bwd_then_resid_bwd(drop):
+    """vlmo_ln_resid_bwd = vlmo_ln_bwd followed by vlmo_resid_bwd on the dx it wrote: dx and dz bit-identical
+    (same arithmetic, same dropout stream), the four column sums equal up to summation order."""
+    g = torch.Generator().manual_seed(11)
+    M, d = 1000, 768
+    dy = torch.randn(M, d, generator=g).to(DEV).bfloat16()
+    x = torch.randn(M, d, generator=g).to(DEV)
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-12).rsqrt()
+    dres = torch.randn(M, d, generator=g).to(DEV)
+    zd = torch.randn(M, d, generator=g).to(DEV).bfloat16()
+    gamma = torch.rand(d, generator=g).to(DEV)
+    scale = (torch.rand(7, generator=g) + 0.5).to(DEV)
+    ridx = torch.randint(0, 7, (M,), generator=g).to(torch.int32).to(DEV)
+    dp = hip.drop_params(drop, True)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    dx0, dw0, db0, dz0, dg0, dpb0 = torch.empty(M, d, device=DEV), z(d), z(d), torch.empty(M, d, device=DEV, dtype=torch.bfloat16), z(d), z(d)
+    hip.ln_bwd(dy, None, x, w, mean, rstd, dres, dx0, dw0, db0, M, d)
+    hip.resid_bwd(dx0, zd, gamma, scale, dz0, dg0, dpb0, M, d, drop=dp, seed=5, row_index=ridx)
+    dx1, dw1, db1, dz1, dg1, dpb1 = torch.empty(M, d, device=DEV), z(d), z(d), torch.empty(M, d, device=DEV, dtype=torch.bfloat16), z(d), z(d)
+    hip.ln_resid_bwd(dy, x, w, mean, rstd, dres, dx1, dw1, db1, zd, gamma, scale, ridx, dz1, dg1, dpb1, M, d, drop=dp, seed=5)
+    assert torch.equal(dx0, dx1) and torch.equal(dz0, dz1)
+    for a, b_ in ((dw0, dw1), (db0, db1), (dg0, dg1), (dpb0, dpb1)):
+        torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-3)
