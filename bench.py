@@ -100,6 +100,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (pairs)')
     ap.add_argument('--preset', default='base')
     ap.add_argument('--tile', type=int, default=None)
+    ap.add_argument('--comm-dtype', choices=['bf16', 'fp32'], default='bf16', help='gradient all-reduce dtype (bf16 packs/unpacks)')
     ap.add_argument('--merge-passes', action='store_true',
                     help='full objective only: batch the backbone passes by mode (V / L / VL): 3 passes instead of 7')
     ap.add_argument('--optimizer', action='store_true',
@@ -149,7 +150,8 @@ def main():
     reducer = None
     if dist is not None:
         from exploremultimodal_amd.dp import GradReducer
-        reducer = GradReducer(model, dist.group.WORLD, reduce_scatter=args.zero2)
+        reducer = GradReducer(model, dist.group.WORLD, reduce_scatter=args.zero2,
+                              comm_dtype=torch.bfloat16 if args.comm_dtype == 'bf16' else torch.float32)
 
     B = args.batch
     batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=args.objective == 'full')
