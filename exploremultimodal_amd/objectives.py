@@ -12,6 +12,39 @@ import torch.nn.functional as F
 from .dvae import create_d_vae  # noqa: F401  (objectives.create_d_vae in the reference)
 
 
+class GatherLayer(torch.autograd.Function):
+    """All-gather that keeps gradients (objectives.py:392-426): ``GatherLayer.apply(feat, group, rank)`` returns the
+    features of every rank concatenated in rank order; backward hands each rank the SUM over ranks of the gradient
+    rows that belong to it.  One ``all_gather_into_tensor`` forward; backward is one ``reduce_scatter_tensor`` (RCCL:
+    1/world of the traffic of the reference's all_reduce + slice; same result) or all_reduce + slice where the
+    backend has no reduce-scatter (gloo)."""
+
+    @staticmethod
+    def forward(ctx, tensor, group, rank):
+        import torch.distributed as dist
+        ctx.batch_size = tensor.shape[0]
+        ctx.group = group
+        ctx.rank = rank
+        world = dist.get_world_size(group)
+        tensor = tensor.contiguous()
+        out = tensor.new_empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]))
+        dist.all_gather_into_tensor(out, tensor, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        import torch.distributed as dist
+        grad_output = grad_output.contiguous()
+        bs = ctx.batch_size
+        if dist.get_backend(ctx.group) == 'nccl':
+            grad_input = grad_output.new_empty((bs,) + tuple(grad_output.shape[1:]))
+            dist.reduce_scatter_tensor(grad_input, grad_output, op=dist.ReduceOp.SUM, group=ctx.group)
+            return grad_input, None, None
+        grad_input = grad_output.clone()
+        dist.all_reduce(grad_input, op=dist.ReduceOp.SUM, group=ctx.group)
+        return grad_input[ctx.rank * bs:(ctx.rank + 1) * bs], None, None
+
+
 def compute_accuracy(logits, target):
     """objectives.py:24-37."""
     preds = logits.argmax(dim=-1)
@@ -46,21 +79,31 @@ def compute_mlm(model, batch):
 
 
 def compute_itc(model, batch):
-    """objectives.py:81-236, naive in-batch branch (global_reduce / momentum / queue are off in
-    conf/train/pretrain_mum.yaml:39-42 and out of scope)."""
+    """objectives.py:81-236: the in-batch branch and the ``global_reduce`` branch (negatives gathered from every
+    rank with GatherLayer, objectives.py:99-108); the momentum / queue branches (off in
+    conf/train/pretrain_mum.yaml:39-42) are out of scope."""
     with torch.no_grad():
         model.itc_temp.data = torch.clamp(model.itc_temp.data, 0, 4.6052)
     temp = model.itc_temp.exp()
-    if model.config.train.global_reduce or model.transformer_m is not None:
-        raise NotImplementedError('global_reduce / momentum ITC branches are out of scope (SURVEY.md 8f)')
+    if model.transformer_m is not None:
+        raise NotImplementedError('the momentum ITC branch is out of scope (SURVEY.md 8f)')
     img_infer = batch.get('_itc_img_infer') or model.infer(batch, infer_mode='img_only')
     txt_infer = batch.get('_itc_txt_infer') or model.infer(batch, infer_mode='txt_only')
     i_feat = model.itc_head(img_infer['co_feats'][:, 0], 'v')
     t_feat = model.itc_head(txt_infer['co_feats'][:, 0], 'l')
     bs = i_feat.size(0)
     sim_targets = torch.arange(bs, device=i_feat.device)
-    sim_i2t = i_feat @ t_feat.t() * temp
-    sim_t2i = sim_i2t.t()
+    if model.config.train.global_reduce:
+        import torch.distributed as dist
+        rank = dist.get_rank()
+        # own rows rolled to the front, so that column j < bs is this rank's pair j (targets stay arange(bs))
+        i_feats = torch.roll(GatherLayer.apply(i_feat, None, rank), -bs * rank, 0)
+        t_feats = torch.roll(GatherLayer.apply(t_feat, None, rank), -bs * rank, 0)
+        sim_i2t = i_feat @ t_feats.t() * temp
+        sim_t2i = t_feat @ i_feats.t() * temp
+    else:
+        sim_i2t = i_feat @ t_feat.t() * temp
+        sim_t2i = sim_i2t.t()
     i2t_loss = F.cross_entropy(sim_i2t, sim_targets)
     t2i_loss = F.cross_entropy(sim_t2i, sim_targets)
     itc_i2t_mean_acc, itc_i2t_count = compute_accuracy(sim_i2t[:, :bs], sim_targets)

@@ -156,3 +156,56 @@ def test_grad_reducer_world2_gloo(mode):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+def _gather_worker(rank, world, port, q):
+    """GatherLayer (objectives.py:392-426) + the global-negatives ITC arithmetic of objectives.py:99-108: the mean over
+    ranks of the per-rank losses and every rank's feature gradient equal the single-process computation on the
+    concatenated batch."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        from exploremultimodal_amd.objectives import GatherLayer
+        bs, dim, temp = 4, 6, 3.0
+        g = torch.Generator().manual_seed(0)
+        I = F.normalize(torch.randn(world * bs, dim, generator=g), dim=1)
+        T = F.normalize(torch.randn(world * bs, dim, generator=g), dim=1)
+        i_feat = I[rank * bs:(rank + 1) * bs].clone().requires_grad_(True)
+        t_feat = T[rank * bs:(rank + 1) * bs].clone().requires_grad_(True)
+        i_all = torch.roll(GatherLayer.apply(i_feat, None, rank), -bs * rank, 0)
+        t_all = torch.roll(GatherLayer.apply(t_feat, None, rank), -bs * rank, 0)
+        tgt = torch.arange(bs)
+        loss = (F.cross_entropy(i_feat @ t_all.t() * temp, tgt) + F.cross_entropy(t_feat @ i_all.t() * temp, tgt)) / 2
+        loss.backward()
+        # single-process reference: the DDP-averaged objective is the mean of the per-rank losses
+        Ir, Tr = I.clone().requires_grad_(True), T.clone().requires_grad_(True)
+        tg = torch.arange(world * bs)
+        ref = (F.cross_entropy(Ir @ Tr.t() * temp, tg) + F.cross_entropy(Tr @ Ir.t() * temp, tg)) / 2
+        ref.backward()
+        tot = loss.detach().clone()
+        dist.all_reduce(tot)
+        assert torch.allclose(tot / world, ref.detach(), atol=1e-6), (tot / world, ref)
+        # gradient of the MEAN loss w.r.t. this rank's features = this rank's autograd gradient / world
+        assert torch.allclose(i_feat.grad / world, Ir.grad[rank * bs:(rank + 1) * bs], atol=1e-6)
+        assert torch.allclose(t_feat.grad / world, Tr.grad[rank * bs:(rank + 1) * bs], atol=1e-6)
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_layer_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'

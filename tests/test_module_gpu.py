@@ -126,3 +126,27 @@ def test_merged_passes_equal_pass_by_pass(golden_dir):
     for k in g0:
         denom = g0[k].norm().item() + 1e-12
         assert (g0[k] - g1[k]).norm().item() / denom <= 2e-2, (k, (g0[k] - g1[k]).norm().item() / denom)
+
+
+def test_itc_global_reduce_branch_single_rank():
+    """compute_itc with config.train.global_reduce (GatherLayer over RCCL, objectives.py:99-108) at world size 1 equals
+    the in-batch branch: same similarities, loss and feature gradients."""
+    import torch.distributed as dist
+    from exploremultimodal_amd import objectives
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        outs = []
+        for glob in (False, True):
+            model, cfg = _build()
+            cfg.train.global_reduce = glob
+            batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, 4, seed=21).items()}
+            ret = objectives.compute_itc(model, batch)
+            ret['itc_task_loss'].backward()
+            outs.append((ret, model.itc_head.dense['v'].weight.grad.clone()))
+        (r0, g0), (r1, g1) = outs
+        assert torch.equal(r0['sim_i2t'], r1['sim_i2t']) and torch.equal(r0['sim_t2i'], r1['sim_t2i'])
+        assert torch.equal(r0['itc_task_loss'], r1['itc_task_loss'])
+        torch.testing.assert_close(g0, g1, rtol=1e-4, atol=1e-6)      # two matmuls instead of one + transpose
+    finally:
+        dist.destroy_process_group()
