@@ -112,6 +112,9 @@ def main():
     ap.add_argument('--objective', default='vl', choices=['vl', 'full'],
                     help="vl = one VL forward_features + backward (headline metric); full = VlmoModule.forward with "
                          "[mlm, mim, itc, itm] incl. the in-loop dVAE tokenizer (BASELINE.json configs[4])")
+    ap.add_argument('--rehearse-gloo', action='store_true',
+                    help='multi-rank REHEARSAL on fewer GPUs than ranks: gloo collectives, ranks share the visible GPUs '
+                         '(exercises the world>1 code paths; the numbers mean nothing)')
     ap.add_argument('--zero2', action='store_true', help='reduce-scatter gradients (ZeRO-2 style partition, ds_stage/l2.yaml)')
     args = ap.parse_args()
 
@@ -122,6 +125,8 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    if args.rehearse_gloo:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -129,7 +134,10 @@ def main():
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from exploremultimodal_amd import engine, hip
     from oracle import synth
@@ -151,7 +159,7 @@ def main():
     if dist is not None:
         from exploremultimodal_amd.dp import GradReducer
         reducer = GradReducer(model, dist.group.WORLD, reduce_scatter=args.zero2,
-                              comm_dtype=torch.bfloat16 if args.comm_dtype == 'bf16' else torch.float32)
+                              comm_dtype=torch.bfloat16 if (args.comm_dtype == 'bf16' and not args.rehearse_gloo) else torch.float32)
 
     B = args.batch
     batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=args.objective == 'full')
