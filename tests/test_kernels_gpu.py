@@ -4,6 +4,7 @@ Tolerances (stated per test): bf16 outputs 2^-8 relative (one rounding) plus the
 fp32-accumulation noise; fp32 outputs 1e-3 relative to the row scale."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -214,18 +215,48 @@ def _attn_case(B, lenA, lenB, heads, seed=0, mask_frac=0.3):
     return qkv, seg.to(DEV), keymask.to(DEV), M, d
 
 
-def _attn_ref(qkv, seg, keymask, heads, d, dctx=None):
-    """fp32 torch reference per sequence (vlmo.py:79-95); returns ctx (+ dqkv)."""
+def _hash32(x):
+    """host replica of csrc/common.h hash32 on uint64 arrays holding 32-bit values"""
+    m = np.uint64(0xFFFFFFFF)
+    x = x ^ (x >> np.uint64(16))
+    x = (x * np.uint64(0x7feb352d)) & m
+    x = x ^ (x >> np.uint64(15))
+    x = (x * np.uint64(0x846ca68b)) & m
+    return x ^ (x >> np.uint64(16))
+
+
+def _attn_keep_mask(seed, nseq, heads, N, thresh):
+    """[nseq, heads, N(q), N(key)] bool: the keep mask of the attention kernels' counter-based dropout
+    (csrc/common.h drop_half / drop_keep, csrc/attention.hip att_drop_group)."""
+    m = np.uint64(0xFFFFFFFF)
+    bh = (np.arange(nseq, dtype=np.uint64)[:, None] * np.uint64(heads) + np.arange(heads, dtype=np.uint64)[None, :])
+    q = np.arange(N, dtype=np.uint64)
+    key = np.arange(N, dtype=np.uint64)
+    group = ((bh[:, :, None, None] * np.uint64(4096) + q[None, None, :, None]) * np.uint64(1024)
+             + (key[None, None, None, :] >> np.uint64(2)))
+    j = key[None, None, None, :] & np.uint64(3)
+    i = (group * np.uint64(2) + (j >> np.uint64(1))) & m
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+    h = _hash32((((i ^ lo) & m) * np.uint64(0x9E3779B9) + hi) & m)
+    field = (h >> (np.uint64(16) * (j & np.uint64(1)))) & np.uint64(0xFFFF)
+    return torch.from_numpy(field >= np.uint64(thresh))
+
+
+def _attn_ref(qkv, seg, keymask, heads, d, dctx=None, keep=None, inv_keep=1.0):
+    """fp32 torch reference per sequence (vlmo.py:79-95); returns ctx (+ dqkv).  keep: optional dropout keep
+    mask [nseq, heads, N, N] applied to the probabilities (vlmo.py:93)."""
     q = qkv.float().clone().requires_grad_(dctx is not None)
     ctx = torch.zeros(q.shape[0], d, device=q.device)
     outs = []
-    for s in seg.tolist():
+    for si, s in enumerate(seg.tolist()):
         rows = torch.cat([torch.arange(s[0], s[0] + s[1]), torch.arange(s[2], s[2] + s[3])]).to(q.device)
         x = q[rows]
         N = x.shape[0]
         qq, kk, vv = [x[:, i * d:(i + 1) * d].reshape(N, heads, 64).transpose(0, 1) for i in range(3)]
         att = (qq @ kk.transpose(-2, -1)) * 64 ** -0.5
         att = att.masked_fill(~keymask[rows].bool()[None, None, :], float('-inf')).softmax(-1)
+        if keep is not None:
+            att = att * keep[si, :, :N, :N].to(att.device) * inv_keep
         o = (att @ vv).transpose(0, 1).reshape(N, d)
         outs.append((rows, o))
     ctx = torch.zeros(q.shape[0], d, device=q.device)
@@ -252,6 +283,29 @@ def test_attention_fwd_bwd(B, lenA, lenB, heads):
     hip.attn_bwd(qkv, ctx, dctx, lse.view(B * heads, -1), seg, B, keymask, dqkv, heads, d, N, 64 ** -0.5)
     scale = ref_dqkv.abs().max().item()
     _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * scale, 'attn dqkv')
+
+
+@pytest.mark.parametrize('B,lenA,lenB,heads', [(2, 64, 197, 2), (3, 16, 17, 1)])
+def test_attention_dropout_forward_and_backward_use_the_same_mask(B, lenA, lenB, heads):
+    """attention dropout (vlmo.py:93): the mask is regenerated in the backward kernels from (seed, sequence, head,
+    query, key); a host replica of the hash gives the fp32 reference the SAME mask, so ctx and dq/dk/dv are checked
+    element-wise -- forward, dQ phase and dK/dV phase must all agree on it."""
+    qkv, seg, keymask, M, d = _attn_case(B, lenA, lenB, heads, seed=17 + B)
+    N = lenA + lenB
+    drop = hip.drop_params(0.1, True)
+    seed = 0x1234567ABCDEF01
+    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B * heads, ((N + 31) // 32) * 32, device=DEV)
+    hip.attn_fwd(qkv, seg, B, keymask, ctx, lse, heads, d, N, 64 ** -0.5, drop=drop, seed=seed)
+    keep = _attn_keep_mask(seed, B, heads, N, drop[0])
+    assert abs(keep.float().mean().item() - 0.9) < 0.01
+    dctx = _rand(M, d, seed=78)
+    ref_ctx, ref_dqkv = _attn_ref(qkv, seg, keymask, heads, d, dctx, keep=keep, inv_keep=drop[1])
+    _close(ctx, ref_ctx, 1 / 64, 1e-2, 'attn ctx (dropout)')
+    dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
+    hip.attn_bwd(qkv, ctx, dctx, lse, seg, B, keymask, dqkv, heads, d, N, 64 ** -0.5, drop=drop, seed=seed)
+    scale = ref_dqkv.abs().max().item()
+    _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * scale, 'attn dqkv (dropout)')
 
 
 def test_attention_dropout_statistics():
