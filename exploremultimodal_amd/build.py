@@ -1,11 +1,14 @@
-"""models/build.py:4-12."""
+"""Model factory with the reference's entry point (models/build.py:4-12): ``build_model(config)`` dispatches on
+``config.model.type`` and raises NotImplementedError for anything but 'VLMO'."""
 from .vlmo_module import VlmoModule
+
+# model type -> constructor taking the whole config node
+_REGISTRY = {'VLMO': VlmoModule}
 
 
 def build_model(config):
-    model_type = config.model.type
-    if model_type == 'VLMO':
-        model = VlmoModule(config=config)
-    else:
-        raise NotImplementedError(f"Unkown model: {model_type}")
-    return model
+    kind = config.model.type
+    ctor = _REGISTRY.get(kind)
+    if ctor is None:
+        raise NotImplementedError(f'Unkown model: {kind}')       # message spelled as upstream: callers grep it
+    return ctor(config=config)
