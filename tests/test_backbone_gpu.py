@@ -180,3 +180,47 @@ def test_grad_reducer_rccl_single_rank():
         if red is not None:
             red.close()
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B,T,fusion', [(1, 5, None), (2, 16, 1), (3, 9, 2), (2, 16, 0)])
+def test_edge_shapes_and_fusion_layer_override_vs_oracle(B, T, fusion):
+    """Ragged cases the reference accepts: batch 1, text shorter than max_text_len (vlmo.py:254 positions 0..T-1),
+    the ``fusion_layer`` call argument (vlmo.py:399-400; 0 is falsy there and means the constructor's value),
+    padded text keys.  Forward and every parameter gradient against the fp32 oracle; tolerance as in the golden
+    tests (bf16 GEMM operands): 3e-2 absolute on outputs of O(1) magnitude, 6 % on gradient norms."""
+    from oracle import vlmo_oracle
+    model, mc = build('mini')
+    model.eval()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    img = torch.randn(B, 3, mc.img_size, mc.img_size, generator=g)
+    ids = torch.randint(1000, mc.vocab_size, (B, T), generator=g)
+    ids[:, 0] = 101
+    tmask = torch.ones(B, T, dtype=torch.int64)
+    if T > 4:
+        tmask[-1, T - 2:] = 0
+        ids[-1, T - 2:] = 0
+    im = torch.ones(B, synth.num_img_tokens(mc), dtype=torch.int64)
+    x, m = model.forward_features(img=img.to(DEV), txt=ids.to(DEV), img_attn_masks=im.to(DEV), txt_attn_masks=tmask.to(DEV),
+                                  fusion_layer=fusion)
+    R = torch.randn(x.shape, generator=g)
+    (x * R.to(DEV)).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    ref, mref = vlmo_oracle.forward_features(sd, mc, img=img, txt=ids, img_attn_masks=im, txt_attn_masks=tmask,
+                                             fusion_layer=fusion)
+    (ref * R).sum().backward()
+    assert x.shape == ref.shape == (B, T + synth.num_img_tokens(mc), mc.embed_dim)
+    assert torch.equal(m.cpu(), mref)
+    assert (x.detach().cpu() - ref.detach()).abs().max().item() <= 3e-2
+    worst = (0.0, '')
+    for k, p in model.named_parameters():
+        gr = sd[k].grad
+        if gr is None or gr.abs().max() == 0:
+            assert p.grad is None or p.grad.abs().max().item() <= 1e-6, k
+            continue
+        assert p.grad is not None, k
+        rel = (p.grad.detach().cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
+        worst = max(worst, (rel, k))
+    assert worst[0] <= 6e-2, worst
+    with pytest.raises(AssertionError):
+        model.forward_features(img=img.to(DEV), txt=ids.to(DEV), img_attn_masks=im.to(DEV), txt_attn_masks=tmask.to(DEV),
+                               fusion_layer=mc.depth + 1)
