@@ -150,3 +150,21 @@ def test_itc_global_reduce_branch_single_rank():
         torch.testing.assert_close(g0, g1, rtol=1e-4, atol=1e-6)      # two matmuls instead of one + transpose
     finally:
         dist.destroy_process_group()
+
+
+def test_objectives_with_nothing_masked_return_python_zero():
+    """objectives.py:67-68, 581-582: with no masked text token / image patch the losses are the python float 0. (not a
+    tensor) and the accuracy counters are 0; the other outputs keep their keys."""
+    model, cfg = _build()
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, 3, seed=5).items()}
+    batch['text_labels_mlm'] = torch.full_like(batch['text_labels_mlm'], -100)
+    batch['text_ids_mlm'] = batch['text_ids'].clone()
+    batch['image_bool_masked_pos'] = torch.zeros_like(batch['image_bool_masked_pos'])
+    batch['itm_neg_idx'] = (torch.tensor([1, 2, 0], device=DEV), torch.tensor([2, 0, 1], device=DEV))
+    ret = model(batch)
+    assert ret['mlm_task_loss'] == 0. and not torch.is_tensor(ret['mlm_task_loss']) and ret['mlm_count'] == 0
+    assert ret['mim_task_loss'] == 0. and not torch.is_tensor(ret['mim_task_loss']) and ret['mim_count'] == 0
+    assert ret['mlm_logits'].shape[0] == 0 and ret['mim_logits'].shape[0] == 0
+    assert torch.isfinite(ret['itc_task_loss']) and torch.isfinite(ret['itm_task_loss'])
+    total = sum(v for k, v in ret.items() if 'task_loss' in k)
+    total.backward()
