@@ -56,15 +56,32 @@ class _Bucket:
         self.used = []
 
 
+class _Arena:
+    """Contiguous storage for the sink buckets of ONE transformer block (its shared parameters and up to three
+    experts): buckets that become ready together are reduced as one collective over their common range."""
+
+    def __init__(self, capacity, device, comm_dtype):
+        self.flat = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.comm = self.flat if comm_dtype == torch.float32 else torch.empty(capacity, dtype=comm_dtype, device=device)
+        self.used = 0
+
+
 class _SinkBucket:
     """Flat fp32 gradient storage of one engine block call signature (see module docstring)."""
 
-    def __init__(self, numel, device, comm_dtype, world):
+    def __init__(self, numel, device, comm_dtype, world, arena=None):
         self.numel = numel
         self.padded = ((numel + world * 8 - 1) // (world * 8)) * (world * 8)
-        self.flat = torch.zeros(self.padded, dtype=torch.float32, device=device)
-        self.comm = self.flat if comm_dtype == torch.float32 else torch.empty(
-            self.padded, dtype=comm_dtype, device=device)
+        self.arena, self.offset = None, 0
+        if arena is not None and arena.used + self.padded <= arena.flat.numel():
+            self.arena, self.offset = arena, arena.used
+            arena.used += self.padded
+            self.flat = arena.flat[self.offset:self.offset + self.padded]
+            self.comm = self.flat if comm_dtype == torch.float32 else arena.comm[self.offset:self.offset + self.padded]
+        else:
+            self.flat = torch.zeros(self.padded, dtype=torch.float32, device=device)
+            self.comm = self.flat if comm_dtype == torch.float32 else torch.empty(
+                self.padded, dtype=comm_dtype, device=device)
         self.expected = 0       # backward calls still to come in this step
         self.fresh = True       # zero before the first accumulation of the step
         self.work = None
@@ -102,6 +119,7 @@ class GradReducer:
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._armed = False
         self.sinks = {}
+        self.arenas = {}
         self._sink_params = set()
         if engine_sink and self.on_gpu:
             from . import engine
@@ -115,6 +133,7 @@ class GradReducer:
         if engine.GRAD_SINK is self:
             engine.GRAD_SINK = None
         self.sinks.clear()
+        self.arenas.clear()
         self._sink_params.clear()
         self._armed = False
 
@@ -167,11 +186,20 @@ class GradReducer:
             self._pending_expect = getattr(self, '_pending_expect', {})
             self._pending_expect[key] = self._pending_expect.get(key, 0) + 1
 
-    def acquire(self, group, numel, device):
+    def acquire(self, group, numel, device, arena_key=None, arena_numel=0):
+        """Flat fp32 storage for one parameter group of a block call.  ``arena_key`` (any hashable naming the block)
+        places the groups of one block next to each other (``arena_numel`` = room for all of them) so that
+        release_all() can reduce them in one collective."""
         key = self._key(group)
         sb = self.sinks.get(key)
         if sb is None:
-            sb = _SinkBucket(numel, device, self.comm_dtype, self.world)
+            arena = None
+            if arena_key is not None and not self.reduce_scatter:
+                arena = self.arenas.get(arena_key)
+                if arena is None:
+                    pad = self.world * 8
+                    arena = self.arenas[arena_key] = _Arena(arena_numel + 4 * pad, device, self.comm_dtype)
+            sb = _SinkBucket(numel, device, self.comm_dtype, self.world, arena)
             sb.expected = getattr(self, '_pending_expect', {}).pop(key, 1)
             self.sinks[key] = sb
             self._sink_params.update(key)
@@ -186,10 +214,48 @@ class GradReducer:
         return sb.flat[:numel]
 
     def release(self, group):
-        sb = self.sinks[self._key(group)]
-        sb.expected -= 1
-        if sb.expected <= 0:
-            self._launch_sink(sb)
+        self.release_all([group])
+
+    def release_all(self, groups):
+        """The backward call that fed these groups has been enqueued.  Buckets whose last contribution of the step
+        this was are reduced now; neighbours in one block arena go out as ONE collective."""
+        ready = []
+        for g in groups:
+            sb = self.sinks[self._key(g)]
+            sb.expected -= 1
+            if sb.expected <= 0:
+                ready.append(sb)
+        ready.sort(key=lambda b: (id(b.arena), b.offset))
+        i = 0
+        while i < len(ready):
+            j = i
+            if ready[i].arena is not None:
+                while (j + 1 < len(ready) and ready[j + 1].arena is ready[i].arena
+                       and ready[j + 1].offset == ready[j].offset + ready[j].padded):
+                    j += 1
+            if j == i:
+                self._launch_sink(ready[i])
+            else:
+                self._launch_range(ready[i:j + 1])
+            i = j + 1
+
+    def _launch_range(self, sbs):
+        """One pack / collective / unpack over the contiguous arena range of several ready buckets."""
+        a = sbs[0].arena
+        lo, hi = sbs[0].offset, sbs[-1].offset + sbs[-1].padded
+        flat, comm = a.flat[lo:hi], a.comm[lo:hi]
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.comm_stream):
+            if comm.data_ptr() != flat.data_ptr():
+                torch.mul(flat, 1.0 / self.world, out=comm)
+            else:
+                flat.mul_(1.0 / self.world)
+            work = dist.all_reduce(comm, group=self.pg, async_op=True)
+            work.wait()
+            if comm.data_ptr() != flat.data_ptr():
+                flat.copy_(comm)
+        for sb in sbs:
+            sb.work, sb.unpacked = work, True
 
     def _launch_sink(self, sb):
         # everything on the communication stream (ordered after the block backward that just finished on the

@@ -289,8 +289,9 @@ class BlockFn(torch.autograd.Function):
         shared_n = 6 * d + 3 * d * d + d * d + d + 3 * d
         exp_n = 2 * hid * d + hid + d
         if sink is not None:    # data-parallel run: accumulate straight into the reducer's persistent flat buckets
-            flats = [sink.acquire(ctx.sink_groups[0], shared_n, dev)] + \
-                    [sink.acquire(g_, exp_n, dev) for g_ in ctx.sink_groups[1:]]
+            akey, aroom = id(params[0]), shared_n + 3 * exp_n       # one arena per block: shared + up to 3 experts
+            flats = [sink.acquire(ctx.sink_groups[0], shared_n, dev, akey, aroom)] + \
+                    [sink.acquire(g_, exp_n, dev, akey, aroom) for g_ in ctx.sink_groups[1:]]
         else:                   # ONE zero-filled flat buffer (one memset) carved into all gradients of the block
             whole = torch.zeros(shared_n + nexp * exp_n, dtype=f32, device=dev)
             flats = [whole[:shared_n]] + [whole[shared_n + i * exp_n: shared_n + (i + 1) * exp_n] for i in range(nexp)]
@@ -350,8 +351,7 @@ class BlockFn(torch.autograd.Function):
                     elif p_.grad.data_ptr() != g_.data_ptr():
                         raise RuntimeError('a parameter of a data-parallel block already holds a foreign .grad; '
                                            'use zero_grad(set_to_none=True)')
-            for g_ in ctx.sink_groups:
-                sink.release(g_)
+            sink.release_all(ctx.sink_groups)
             return (dx0, None) + (None,) * len(grads)
         return (dx0, None, *grads)
 
