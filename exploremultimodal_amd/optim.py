@@ -208,6 +208,12 @@ class FusedAdam(torch.optim.Optimizer):
                 a.inv_bc1 = a.inv_bc2 = 1.0
             a.adam_w_mode = self.adam_w_mode
             hip.mt_adam(tl, a, ctl if use_ctl else None)
+        # the kernel wrote the parameters and moments behind autograd's back: bump their version counters, which is
+        # what invalidates the engine's cached bf16 weight shadows (engine.ShadowCache) and any saved-tensor checks
+        touched = [p for _, p, _ in items]
+        for _, _, st in items:
+            touched += [st['exp_avg'], st['exp_avg_sq']]
+        torch.autograd.graph.increment_version(touched)
         for _, _, st in items:
             st['step'] += 1        # host-side counters (GradScaler-style skips are not counted back)
         self.last_ctl = ctl if use_ctl else None

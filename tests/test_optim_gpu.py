@@ -96,6 +96,32 @@ def test_non_finite_gradients_skip_the_step():
     assert torch.count_nonzero(ours.state[ps[0]]['exp_avg']).item() == 0
 
 
+def test_step_bumps_version_counters_so_weight_shadows_refresh():
+    """The kernel updates parameters through raw pointers; without a version bump the engine would keep multiplying
+    with the bf16 shadow of the OLD weights (engine.ShadowCache keys on ``_version``)."""
+    from exploremultimodal_amd.build import build_model
+    from oracle import synth
+    cfg = synth.make_config('mini', drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0)
+    torch.manual_seed(0)
+    model = build_model(cfg).to(DEV).train()
+    opt = optim.FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-2)
+    batch = synth.synth_batch(cfg.model, 2, seed=0)
+    img, ids, tmask = batch['image'].to(DEV), batch['text_ids'].to(DEV), batch['text_mask'].to(DEV)
+    imask = torch.ones(2, synth.num_img_tokens(cfg.model), dtype=torch.int64, device=DEV)
+    fwd = lambda m: m.transformer.forward_features(img=img, txt=ids, img_attn_masks=imask, txt_attn_masks=tmask)[0]
+    w = model.transformer.blocks[0].attn.qkv.weight
+    v0 = w._version
+    fwd(model).square().mean().backward()
+    opt.step()
+    assert w._version > v0
+    with torch.no_grad():
+        after = fwd(model)
+        torch.manual_seed(1)
+        twin = build_model(cfg).to(DEV).train()
+        twin.load_state_dict(model.state_dict())
+        assert torch.equal(after, fwd(twin))       # same weights -> same forward: no stale shadow was used
+
+
 def test_state_dict_round_trip_and_torch_layout():
     ps = _params(5, [(50, 20), (20,)])
     ours = optim.FusedAdam(ps, lr=1e-2, weight_decay=0.1)

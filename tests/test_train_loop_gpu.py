@@ -1,0 +1,103 @@
+"""End-to-end loop in the shape of train/pretrain/multimodal.py:233-333 on synthetic data: DataLoaderX hand-off ->
+VlmoModule.forward([mlm, mim, itc, itm]) -> sum of task losses -> NativeScalerWithGradNormCount (backward, fused
+clip, fused AdamW) with the cosine schedule -> save_model / auto_load_model resume."""
+import types
+
+import pytest
+import torch
+from torch.utils.data import Dataset
+
+from exploremultimodal_amd import checkpoint, optim
+from exploremultimodal_amd.build import build_model
+from exploremultimodal_amd.prefetch import DataLoaderX
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+NS = types.SimpleNamespace
+
+
+class _Synthetic(Dataset):
+    def __init__(self, mc, n):
+        self.b = synth.synth_batch(mc, n, seed=11)
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {k: v[i] for k, v in self.b.items()}
+
+
+def _setup(tmp_path, tag='loop'):
+    cfg = synth.make_config('mini', loss_names=['mlm', 'mim', 'itc', 'itm'], drop_rate=0.0, attn_drop_rate=0.0,
+                            drop_path_rate=0.0)
+    cfg.train.merge_passes = True
+    cfg.train.auto_resume, cfg.train.resume, cfg.train.epochs, cfg.train.start_epoch = True, '', 4, 0
+    cfg.tag, cfg.exp_dir, cfg.output_dir = tag, str(tmp_path), str(tmp_path / 'run')
+    torch.manual_seed(0)
+    model = build_model(cfg).to(DEV).train()
+    tcfg = NS(opt=NS(name='fusedadamw', eps=1e-8, betas=[0.9, 0.98], momentum=0.9), weight_decay=0.01, base_lr=2e-3,
+              lr_mult_head=1, lr_mult_fusion=1)
+    opt = optim.create_optimizer(tcfg, model)
+    return cfg, model, opt
+
+
+class _Sched:
+    """The reference assigns lr per iteration from the cosine table (multimodal.py:253-262)."""
+
+    def __init__(self, opt, table):
+        self.opt, self.table, self.it = opt, table, 0
+        self.base = [g['lr'] for g in opt.param_groups]
+
+    def step(self):
+        f = self.table[min(self.it, len(self.table) - 1)]
+        for g, b in zip(self.opt.param_groups, self.base):
+            g['lr'] = b * f
+        self.it += 1
+
+    def state_dict(self):
+        return {'it': self.it}
+
+    def load_state_dict(self, sd):
+        self.it = sd['it']
+
+
+def test_synthetic_pretraining_loop_learns_and_resumes(tmp_path):
+    cfg, model, opt = _setup(tmp_path)
+    loader = DataLoaderX(0, max_prefetch=2, dataset=_Synthetic(cfg.model, 8), batch_size=4, shuffle=False)
+    sched = _Sched(opt, optim.cosine_scheduler(1.0, 0.1, epochs=4, niter_per_ep=2, warmup_epochs=1))
+    scaler = optim.NativeScalerWithGradNormCount()
+    losses = []
+    for epoch in range(3):
+        for batch in loader:
+            sched.step()
+            ret = model(batch)
+            loss = sum(v for k, v in ret.items() if 'task_loss' in k)
+            norm = scaler(loss, opt, clip_grad=5.0, parameters=model.parameters())
+            opt.zero_grad(set_to_none=True)
+            assert torch.isfinite(norm).item()
+            losses.append(loss.item())
+        checkpoint.save_model(cfg, epoch, model, model, opt, sched, scaler)
+    loader.shutdown()
+    assert sum(losses[-2:]) < sum(losses[:2]), losses
+    # resume into a freshly initialised model / optimizer
+    cfg2, model2, opt2 = _setup(tmp_path)
+    sched2 = _Sched(opt2, sched.table)
+    match = checkpoint.auto_load_model(cfg2, model2, model2, opt2, sched2, optim.NativeScalerWithGradNormCount())
+    assert cfg2.train.start_epoch == 3 and sched2.it == sched.it
+    assert all(k.startswith('d_vae.') for k in match.missing_keys) and not match.unexpected_keys
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        if not k.startswith('d_vae.'):
+            assert torch.equal(a, b), k
+    s1, s2 = opt.state_dict()['state'], opt2.state_dict()['state']
+    assert set(s1) == set(s2) and all(torch.equal(s1[i]['exp_avg'].cpu(), s2[i]['exp_avg'].cpu()) for i in s1)
+    # one more step from the resumed state behaves like one more step of the original
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, 4, seed=11).items()}
+    batch['itm_neg_idx'] = (torch.tensor([1, 0, 3, 2], device=DEV), torch.tensor([2, 3, 0, 1], device=DEV))
+    out = []
+    for m in (model, model2):
+        ret = m(dict(batch))
+        out.append({k: float(v) for k, v in ret.items() if 'task_loss' in k})
+    for k in out[0]:
+        assert abs(out[0][k] - out[1][k]) <= 1e-5 * max(1.0, abs(out[0][k])), (k, out)
