@@ -63,11 +63,30 @@ class _Sched:
         self.it = sd['it']
 
 
-def test_synthetic_pretraining_loop_learns_and_resumes(tmp_path):
+@pytest.mark.parametrize('with_reducer', [False, True])
+def test_synthetic_pretraining_loop_learns_and_resumes(tmp_path, with_reducer):
     cfg, model, opt = _setup(tmp_path)
+    reducer = None
+    if with_reducer:        # the data-parallel path at world size 1: engine sink buckets + RCCL + fused optimizer
+        import os
+        import torch.distributed as dist
+        from exploremultimodal_amd.dp import GradReducer
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29549')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        reducer = GradReducer(model)
+    try:
+        _run_loop(tmp_path, cfg, model, opt, reducer)
+    finally:
+        if reducer is not None:
+            import torch.distributed as dist
+            reducer.close()
+            dist.destroy_process_group()
+
+
+def _run_loop(tmp_path, cfg, model, opt, reducer):
     loader = DataLoaderX(0, max_prefetch=2, dataset=_Synthetic(cfg.model, 8), batch_size=4, shuffle=False)
     sched = _Sched(opt, optim.cosine_scheduler(1.0, 0.1, epochs=4, niter_per_ep=2, warmup_epochs=1))
-    scaler = optim.NativeScalerWithGradNormCount()
+    scaler = optim.NativeScalerWithGradNormCount(reducer)
     losses = []
     for epoch in range(3):
         for batch in loader:
