@@ -298,6 +298,13 @@ class VLMO(nn.Module):
             raise IndexError(f'text length {txt.shape[1]} exceeds max_text_len {self.max_text_len}')
         return dev
 
+    def invalidate_weight_shadows(self):
+        """Drop the cached bf16 copies of the GEMM weights.  They are re-cast automatically when a parameter's
+        autograd version counter changes (optimizer steps, ``load_state_dict``, any in-place torch op); code that
+        writes weights through ``param.data`` or raw pointers must call this (or
+        ``torch.autograd.graph.increment_version``)."""
+        self._shadows.clear()
+
     def _run_blocks(self, x, plan, mode, fusion_layer, layers, seed):
         layers = list(layers)
         todo = [(i,) + tuple(self._routes(i, mode, fusion_layer, plan)) for i in layers]
