@@ -3,14 +3,30 @@
 // host issues one FFI call per block and stays far ahead of the GPU.
 #include "common.h"
 #include "vlmo_hip.h"
+#include <algorithm>
+#include <map>
+#include <vector>
 
 namespace {
 
+// fork / join events of the calling thread, one set per device (a process may drive several GPUs)
 struct Events {
     hipEvent_t fork = nullptr, join = nullptr;
+    std::vector<hipEvent_t> pool;      // vlmo_stack_bwd: fork / done event per deferred batch
+    hipEvent_t get(size_t i) {
+        while (pool.size() <= i) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            pool.push_back(e);
+        }
+        return pool[i];
+    }
 };
 Events& events() {
-    static thread_local Events e;
+    static thread_local std::map<int, Events> per_device;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Events& e = per_device[dev];
     if (!e.fork) {
         (void)hipEventCreateWithFlags(&e.fork, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&e.join, hipEventDisableTiming);
@@ -74,7 +90,6 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
     // expert FFNs: all experts of the block in ONE grouped launch per linear (row ranges, weights and biases
     // differ per expert; a launch costs at least one tile time, so per-expert launches of the 4 096 text rows
     // and the 12 608 image rows would cost two)
-    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 4, "vlmo_block_fwd: 1..4 experts per block");
     const void *a1[4], *w1[4], *a2[4], *w2[4];
     int32_t rows[4];
     VlmoEpilogue e1[4], e2[4];
@@ -144,13 +159,13 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     // The column folds of the LayerNorm / LayerScale / bias gradients are deferred to the side stream (after
     // the next fork) when the workspace has a slot per producer; else they run in place on the main stream.
     const int64_t slot = reduce_ws_need(2 * d);
-    const bool defer = side != st && b->ws_bytes >= (int64_t)(3 + b->n_experts) * slot && b->n_experts <= 3;
+    const bool defer = side != st && b->ws_bytes >= (int64_t)(3 + b->n_experts) * slot;
     auto ws_slot = [&](int k) { return defer ? (float*)((char*)b->ws_main + k * slot) : b->ws_main; };
     PartialReduce pend[6];
     auto arm = [&](int k) { vlmo_defer_reduce = defer ? &pend[k] : nullptr; };
     // ---- FFN half: per-expert residual-branch backward, then the two dgrad GEMMs of ALL experts as grouped
     // launches on the main stream and every expert's weight gradients on the side stream
-    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 3, "vlmo_block_bwd: 1..3 experts per block");
+    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 2, "vlmo_block_bwd: 1..2 experts per block");
     const void *ag[4], *wg[4], *af[4], *wf[4];
     int32_t rows[4];
     VlmoEpilogue eg[4], ef[4];
@@ -228,4 +243,214 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         (void)hipStreamWaitEvent(st, ev.join, 0);
     }
     return 0;
+}
+
+
+// ================================================================ whole block stacks in one call
+// vlmo_stack_fwd / vlmo_stack_bwd run the blocks of one backbone pass (vlmo.py:402-411) from native code:
+// one FFI call per pass and direction.  The backward enqueues the activation-gradient chains of all blocks
+// back to back on the caller's stream and DEFERS every block's parameter-gradient work -- the four to six
+// weight-gradient GEMMs and all bias / layer-scale / LayerNorm-weight column sums -- to the side stream in
+// batches of `wgrad_batch` blocks: ONE vlmo_gemm_tn_multi launch (216 output tiles for two VLMo-Base blocks:
+// the chip is full without splitting the token dimension) and ONE vlmo_colwork_multi launch per batch.
+namespace {
+
+struct Deferred {
+    std::vector<VlmoTnProblem> tn;
+    std::vector<VlmoColJob> col;
+    std::vector<int> blocks;
+};
+
+void push_fold(Deferred& D, const PartialReduce& r) {
+    if (!r.ws) return;
+    VlmoColJob j{};
+    j.kind = 0;
+    j.ld = r.ncols;
+    j.src = r.ws;
+    j.rows = r.nblk;
+    j.ncols = r.ncols;
+    j.out[0] = r.out0, j.out[1] = r.out1, j.out[2] = r.out2, j.out[3] = r.out3;
+    j.n0 = r.n0;
+    D.col.push_back(j);
+}
+void push_colsum(Deferred& D, const void* x, int ld, int rows, int ncols, float* out) {
+    VlmoColJob j{};
+    j.kind = 1;
+    j.ld = ld;
+    j.src = x;
+    j.rows = rows;
+    j.ncols = ncols;
+    j.out[0] = out;
+    j.n0 = ncols;
+    D.col.push_back(j);
+}
+void push_tn(Deferred& D, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2) {
+    D.tn.push_back(VlmoTnProblem{A, B, C, lda, ldb, ldc, M, N1, N2, 1.f, 1});
+}
+
+// activation-gradient chain of one block on `st`; parameter-gradient work is appended to D
+int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
+    const int M = b->M, d = b->d, hid = b->hidden;
+    const int64_t slot = reduce_ws_need(2 * d);
+    VLMO_CHECK_ARG(b->dx2 && b->dx1 && b->dx0, "vlmo_stack_bwd: null gradient buffers");
+    VLMO_CHECK_ARG(b->n_experts >= 1 && b->n_experts <= 2, "vlmo_stack_bwd: 1..2 experts per block");
+    VLMO_CHECK_ARG(b->ws_main && b->ws_bytes >= (int64_t)(3 + b->n_experts) * slot,
+                   "vlmo_stack_bwd: column workspace too small (need %lld bytes per block)",
+                   (long long)((3 + b->n_experts) * slot));
+    auto ws_slot = [&](int k) { return (float*)((char*)b->ws_main + k * slot); };
+    PartialReduce pend;
+    auto arm = [&]() {
+        pend = PartialReduce{};
+        vlmo_defer_reduce = &pend;
+    };
+    auto collect = [&]() {
+        vlmo_defer_reduce = nullptr;
+        push_fold(D, pend);
+    };
+    const void *ag[4], *wg[4], *af[4], *wf[4];
+    int32_t rows[4];
+    VlmoEpilogue eg[4], ef[4];
+    for (int x = 0; x < b->n_experts; ++x) {
+        const size_t r0 = b->exp_row0[x];
+        const int n = rows[x] = b->exp_rows[x];
+        arm();
+        TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2,
+                           b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr),
+                           b->row_index ? b->row_index + r0 : nullptr, bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d,
+                           b->drop_thresh, b->inv_keep, b->seed + 21 + 2 * x, ws_slot(2 + x), slot, st));
+        collect();
+        ag[x] = bp(b->dz2, r0, d, 2);
+        wg[x] = b->w2T[x];
+        VlmoEpilogue& e = eg[x] = epi();
+        e.out = bp(b->du, r0, hid, 2);
+        e.ldo = hid;
+        e.aux = bp(b->u, r0, hid, 2);
+        e.ld2 = hid;
+        e.drop_thresh = b->drop_thresh;
+        e.inv_keep = b->inv_keep;
+        e.seed = b->seed + 20 + 2 * x;
+        af[x] = bp(b->du, r0, hid, 2);
+        wf[x] = b->w1T[x];
+        VlmoEpilogue& f = ef[x] = epi();
+        f.out = bp(b->dy2, r0, d, 2);
+        f.ldo = d;
+        push_tn(D, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid);
+        push_tn(D, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d);
+        push_colsum(D, bp(b->du, r0, hid, 2), hid, n, hid, b->db1[x]);
+    }
+    TRY(vlmo_gemm_nt_grouped(VLMO_EPI_DGELU, VLMO_BF16, b->tile, b->n_experts, ag, d, wg, d, rows, hid, d, eg, st));
+    TRY(vlmo_gemm_nt_grouped(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->n_experts, af, hid, wf, hid, rows, d, hid, ef, st));
+    arm();
+    TRY(vlmo_ln_resid_bwd(b->dy2, b->x1, b->n2w, b->mean2, b->rstd2, b->dx2, b->dx1, b->dn2w, b->dn2b, b->zd1, b->g1,
+                          b->rs1, b->row_index, b->dz1, b->dg1, b->dproj_b, b->drop_thresh, b->inv_keep, b->seed + 1, M, d,
+                          ws_slot(0), 2 * slot, st));
+    collect();
+    {
+        VlmoEpilogue e = epi();
+        e.out = b->dctx;
+        e.ldo = d;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dz1, d, b->proj_wT, d, M, d, d, &e, st));
+    }
+    const float scale = 1.0f / sqrtf((float)(d / b->heads));
+    for (int a = 0; a < b->n_attn; ++a)
+        TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
+                          b->dqkv, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
+                          b->seed + 11 + a, st));
+    push_tn(D, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d);
+    push_tn(D, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d);
+    push_colsum(D, b->dqkv, 3 * d, M, 3 * d, b->dqkv_b);
+    {
+        VlmoEpilogue e = epi();
+        e.out = b->dy1;
+        e.ldo = d;
+        TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dqkv, 3 * d, b->qkv_wT, 3 * d, M, d, 3 * d, &e, st));
+    }
+    arm();
+    TRY(vlmo_ln_bwd(b->dy1, 0, nullptr, b->x, b->n1w, b->mean1, b->rstd1, b->dx1, b->dx0, b->dn1w, b->dn1b, M, d,
+                    ws_slot(2 + b->n_experts), slot, st));
+    collect();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vlmo_stack_fwd(const VlmoStackDesc* s, hipStream_t st) {
+    VLMO_CHECK_ARG(s && s->blocks && s->n_blocks >= 1, "vlmo_stack_fwd: empty stack");
+    for (int i = 0; i < s->n_blocks; ++i)
+        if (int rc = vlmo_block_fwd(&s->blocks[i], st)) return rc;
+    return 0;
+}
+
+extern "C" int vlmo_stack_bwd(const VlmoStackDesc* s, hipStream_t st) {
+    VLMO_CHECK_ARG(s && s->blocks && s->n_blocks >= 1, "vlmo_stack_bwd: empty stack");
+    const int nb = s->n_blocks;
+    const int batch = s->wgrad_batch >= 1 ? s->wgrad_batch : 1;
+    const int nsets = s->n_tmp_sets >= 1 ? s->n_tmp_sets : 1;
+    hipStream_t side = s->side_stream ? s->side_stream : st;
+    const bool two = side != st;
+    VLMO_CHECK_ARG(!two || nsets > batch || nb <= nsets,
+                   "vlmo_stack_bwd: %d temporary sets cannot cover deferred batches of %d blocks", nsets, batch);
+    Events& ev = events();
+    Deferred D;
+    std::vector<int> batch_of(nb, -1);
+    int n_batches = 0, waited_upto = -1;
+    auto flush = [&]() -> int {
+        if (D.blocks.empty()) return 0;
+        if (two) {
+            hipEvent_t f = ev.get(2 * n_batches);
+            (void)hipEventRecord(f, st);
+            (void)hipStreamWaitEvent(side, f, 0);
+        }
+        // longest reductions first: with more tiles than CUs the short ones back-fill
+        std::stable_sort(D.tn.begin(), D.tn.end(), [](const VlmoTnProblem& a, const VlmoTnProblem& b) { return a.M > b.M; });
+        TRY(vlmo_gemm_tn_multi(VLMO_BF16, D.tn.data(), (int)D.tn.size(), side));
+        TRY(vlmo_colwork_multi(VLMO_BF16, D.col.data(), (int)D.col.size(), side));
+        if (two) (void)hipEventRecord(ev.get(2 * n_batches + 1), side);
+        if (s->grad_ready)
+            for (int i : D.blocks)
+                if (s->grad_ready[i]) (void)hipEventRecord((hipEvent_t)s->grad_ready[i], side);
+        ++n_batches;
+        D.tn.clear();
+        D.col.clear();
+        D.blocks.clear();
+        return 0;
+    };
+    for (int k = 0; k < nb; ++k) {
+        const int i = nb - 1 - k;
+        if (two && k >= nsets) {
+            // this block reuses the temporaries of the block processed nsets steps ago: its deferred work must be done
+            int need = batch_of[k - nsets];
+            if (need < 0 || need >= n_batches) {
+                TRY(flush());
+                need = n_batches - 1;
+            }
+            if (need > waited_upto) {
+                (void)hipStreamWaitEvent(st, ev.get(2 * need + 1), 0);
+                waited_upto = need;
+            }
+        }
+        TRY(block_dgrad_chain(&s->blocks[i], st, D));
+        D.blocks.push_back(i);
+        batch_of[k] = n_batches;
+        if ((int)D.blocks.size() >= batch || k == nb - 1) TRY(flush());
+    }
+    if (two && n_batches > 0) (void)hipStreamWaitEvent(st, ev.get(2 * (n_batches - 1) + 1), 0);
+    return 0;
+}
+
+extern "C" int vlmo_event_create(void** out) {
+    VLMO_CHECK_ARG(out, "vlmo_event_create: null out");
+    hipEvent_t e = nullptr;
+    hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) {
+        vlmo_set_error("vlmo_event_create: %s", hipGetErrorString(rc));
+        return (int)rc;
+    }
+    *out = e;
+    return 0;
+}
+extern "C" int vlmo_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : 0; }
+extern "C" int vlmo_stream_wait_event(hipStream_t stream, void* ev) {
+    VLMO_CHECK_ARG(ev, "vlmo_stream_wait_event: null event");
+    return (int)hipStreamWaitEvent(stream, (hipEvent_t)ev, 0);
 }

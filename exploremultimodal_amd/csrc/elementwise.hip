@@ -148,6 +148,77 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     }
 }
 
+// Batched column work (vlmo_colwork_multi): job q owns the workgroups [b0[q], b0[q+1]), laid out gx[q] column
+// groups x row slices of rps[q] rows.  block (64, 4).
+constexpr int MAX_COL_JOBS = 32;
+struct ColMulti {
+    int n;
+    int b0[MAX_COL_JOBS + 1];
+    int gx[MAX_COL_JOBS], rps[MAX_COL_JOBS];
+    VlmoColJob j[MAX_COL_JOBS];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void colwork_multi_kernel(const ColMulti cm) {
+    typedef typename Elem<T>::v8 v8;
+    __shared__ float red[4][64][8];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_COL_JOBS; ++q)
+        if (q < cm.n && (int)blockIdx.x >= cm.b0[q]) ji = q;
+    ji = __builtin_amdgcn_readfirstlane(ji);
+    const VlmoColJob& J = cm.j[ji];
+    const int local = blockIdx.x - cm.b0[ji], gx = cm.gx[ji], rps = cm.rps[ji];
+    const int bx = local % gx, by = local / gx;
+    const int r0 = by * rps, r1 = min(J.rows, r0 + rps);
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    if (J.kind == 0) {
+        const float* ws = (const float*)J.src;
+        const int c = bx * 64 + tx;
+        float a = 0.f;
+        if (c < J.ncols)
+            for (int r = r0 + ty; r < r1; r += 4) a += ws[(size_t)r * J.ld + c];
+        red[ty][tx][0] = a;
+        __syncthreads();
+        if (ty == 0 && c < J.ncols) {
+            const float t = red[0][tx][0] + red[1][tx][0] + red[2][tx][0] + red[3][tx][0];
+            const int k = c / J.n0;
+            float* base = J.out[k];
+            if (base) atomicAdd(base + (c - k * J.n0), t);
+        }
+    } else {
+        const T* x = (const T*)J.src;
+        const int c8 = (bx * 64 + tx) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c8 < J.ncols) {
+            for (int mb = r0 + ty; mb < r1; mb += 16) {
+                v8 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = mb + 4 * k;
+                    v[k] = *(const v8*)(x + (size_t)(m < r1 ? m : mb) * J.ld + c8);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (mb + 4 * k < r1)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) acc[jj] += (float)v[k][jj];
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) red[ty][tx][jj] = acc[jj];
+        __syncthreads();
+        if (ty == 0 && c8 < J.ncols) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int c = c8 + jj;
+                const int k = c / J.n0;
+                float* base = J.out[k];
+                if (base) atomicAdd(base + (c - k * J.n0), red[0][tx][jj] + red[1][tx][jj] + red[2][tx][jj] + red[3][tx][jj]);
+            }
+        }
+    }
+}
+
 // 32x32 tile transpose through LDS; block (32, 8)
 template <typename T>
 __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ src, int rows, int cols,
@@ -459,6 +530,40 @@ extern "C" int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, 
     }
     VLMO_CHECK_LAUNCH("vlmo_colsum");
     return reduce_partials(ws, grid.y, N, out, N, nullptr, stream);
+}
+
+extern "C" int vlmo_colwork_multi(int dtype, const VlmoColJob* jobs, int n, hipStream_t stream) {
+    VLMO_CHECK_ARG(jobs && n >= 1, "vlmo_colwork_multi: no jobs");
+    VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_colwork_multi: dtype must be bf16 or f16");
+    for (int q0 = 0; q0 < n; q0 += MAX_COL_JOBS) {
+        const int nq = n - q0 < MAX_COL_JOBS ? n - q0 : MAX_COL_JOBS;
+        ColMulti cm{};
+        cm.n = nq;
+        int b = 0;
+        for (int q = 0; q < nq; ++q) {
+            const VlmoColJob& J = jobs[q0 + q];
+            VLMO_CHECK_ARG(J.src && J.rows > 0 && J.ncols > 0 && J.n0 > 0 && J.ncols <= 4 * J.n0 && J.ld >= J.ncols,
+                           "vlmo_colwork_multi: bad job %d", q0 + q);
+            VLMO_CHECK_ARG(J.kind == 0 || (J.kind == 1 && J.ncols % 8 == 0 && J.ld % 8 == 0),
+                           "vlmo_colwork_multi: job %d: matrix column sums need ncols, ld multiples of 8", q0 + q);
+            cm.j[q] = J;
+            cm.gx[q] = J.kind == 0 ? (J.ncols + 63) / 64 : (J.ncols / 8 + 63) / 64;
+            int slices = J.kind == 0 ? (J.rows >= 64 ? 8 : 1) : (J.rows >= 2048 ? 32 : (J.rows >= 256 ? 8 : 1));
+            int rps = (J.rows + slices - 1) / slices;
+            if (J.kind == 1) rps = ((rps + 15) / 16) * 16;
+            slices = (J.rows + rps - 1) / rps;
+            cm.rps[q] = rps;
+            cm.b0[q] = b;
+            b += cm.gx[q] * slices;
+        }
+        for (int q = nq; q <= MAX_COL_JOBS; ++q) cm.b0[q] = b;
+        if (dtype == VLMO_F16)
+            hipLaunchKernelGGL(colwork_multi_kernel<f16>, dim3(b), dim3(64, 4), 0, stream, cm);
+        else
+            hipLaunchKernelGGL(colwork_multi_kernel<bf16>, dim3(b), dim3(64, 4), 0, stream, cm);
+        VLMO_CHECK_LAUNCH("vlmo_colwork_multi");
+    }
+    return 0;
 }
 
 extern "C" int vlmo_cast_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT,

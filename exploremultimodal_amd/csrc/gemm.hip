@@ -434,8 +434,11 @@ struct GemmTN {
     int M, N1, N2, lda, ldb, ldc;
     int kt_per_split, tiles;
     float alpha;
-    float* slab;     // [splits, N1, N2] fp32 partial products (plain stores) or NULL (atomics into C)
+    float* slab;     // [splits, N1, N2] fp32 partial products (plain stores) or NULL (see mode)
+    int mode;        // without a slab: 0 = fp32 atomics into C, 1 = C += alpha * acc (this workgroup owns the
+                     // tile: no K split), 2 = C = alpha * acc
 };
+enum { TN_ATOMIC = 0, TN_ACCUM = 1, TN_STORE = 2 };
 
 // dual-use 256-byte-row image: chunk swizzle serving the transposed reads
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -443,7 +446,7 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row
 // Output tile BM x BN (multiples of 128) per workgroup of WM x WN waves; each operand's K-tile (64 token rows)
 // is staged as BM/128 resp. BN/128 side-by-side sub-images of [64 rows][128 columns] in the dual-use swizzle.
 template <typename T, int BM, int BN, int WM, int WN, bool PP = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p) {
+__device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
     typedef typename Elem<T>::v8 v8;
     typedef typename Elem<T>::v4 v4;
     constexpr int NW = WM * WN;
@@ -460,7 +463,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p
     // 1-D grid of splits x tiles, remapped so that the workgroups one XCD runs are consecutive
     // (split-major): the ~32 tiles of one K-split share that split's token rows through the XCD's L2
     const int tiles_n = (p.N2 + BN - 1) / BN;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int split = lid / p.tiles, tile = lid - split * p.tiles;
     const int n1_0 = (tile / tiles_n) * BM, n2_0 = (tile % tiles_n) * BN;
     const int nk_total = (p.M + 63) >> 6;
@@ -617,13 +619,44 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p
             for (int r = 0; r < 16; ++r) {
                 const int gm = n1_0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (gm < p.N1 && gn < p.N2) {
+                    float* c = p.C + (size_t)gm * p.ldc + gn;
                     if (p.slab)
                         p.slab[((size_t)split * p.N1 + gm) * p.N2 + gn] = acc[i][j][r];
+                    else if (p.mode == TN_STORE)
+                        *c = p.alpha * acc[i][j][r];
+                    else if (p.mode == TN_ACCUM)
+                        *c += p.alpha * acc[i][j][r];
                     else
-                        atomicAdd(p.C + (size_t)gm * p.ldc + gn, p.alpha * acc[i][j][r]);
+                        atomicAdd(c, p.alpha * acc[i][j][r]);
                 }
             }
         }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool PP = false>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p) {
+    gemm_tn_body<T, BM, BN, WM, WN, PP>(p, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Up to MAX_TN_PROBS weight-gradient problems in ONE launch of 256x256 tiles (the four to six linears of one or
+// two transformer blocks): problem q owns the logical workgroups [t0[q], t0[q+1]).  A single weight gradient of
+// VLMo-Base has 9-36 output tiles, so on its own it needs a 7-way split of the token dimension (slabs + a reduction
+// pass, or atomics) to occupy 256 CUs; the gradients of two blocks together have 216 tiles and need no split at all.
+constexpr int MAX_TN_PROBS = 16;
+struct GemmTNMulti {
+    int n;
+    int t0[MAX_TN_PROBS + 1];
+    GemmTN p[MAX_TN_PROBS];
+};
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti mp) {
+    const int lid_all = xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_TN_PROBS; ++q)
+        if (q < mp.n && lid_all >= mp.t0[q]) gi = q;
+    gi = __builtin_amdgcn_readfirstlane(gi);
+    gemm_tn_body<T, 256, 256, 2, 4, true>(mp.p[gi], lid_all - mp.t0[gi]);
 }
 
 // C[r, c] += alpha * sum_s slab[s, r, c]   (one float4 per thread)
@@ -891,7 +924,7 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     // big enough and there is more than one split; else straight into C with fp32 atomics.  Measured on MI355X:
     // 7 splits of a 3072x768 gradient as atomics cost ~30 us of a 135 us launch (memory-side atomic rate).
     const bool use_slab = ws && pl.splits > 1 && N2 % 4 == 0 && ldc % 4 == 0 && ws_bytes >= (int64_t)pl.splits * N1 * N2 * 4;
-    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, pl.per, pl.tiles, alpha, use_slab ? ws : nullptr};
+    GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, pl.per, pl.tiles, alpha, use_slab ? ws : nullptr, TN_ATOMIC};
     dim3 grid(pl.tiles * pl.splits);
     ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
     if (pl.big) {
@@ -918,6 +951,78 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
         const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(rg), dim3(256), 0, stream, ws, pl.splits, N1, N2, C, ldc, alpha);
         VLMO_CHECK_LAUNCH("vlmo_gemm_tn(reduce)");
+    }
+    return 0;
+}
+
+// Weight gradients of several linears in one launch (see gemm_tn_multi_kernel).  Tiles are 256x256; when the
+// problems together have fewer than ~3/4 of the CUs' worth of tiles every problem's token dimension is split
+// (fp32 atomics), else each tile is owned by one workgroup and written / accumulated in place.
+extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, hipStream_t stream) {
+    VLMO_CHECK_ARG(probs && n >= 1, "vlmo_gemm_tn_multi: no problems");
+    VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn_multi: dtype must be bf16 or f16");
+    static bool attr = false;
+    if (!attr) {
+        constexpr int LDS = 2 * 4 * 64 * 256;
+        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+    }
+    for (int q0 = 0; q0 < n; q0 += MAX_TN_PROBS) {
+        const int nq = n - q0 < MAX_TN_PROBS ? n - q0 : MAX_TN_PROBS;
+        long tiles_all = 0;
+        int min_nk = 1 << 30;
+        double flops = 0;
+        for (int q = 0; q < nq; ++q) {
+            const VlmoTnProblem& r = probs[q0 + q];
+            VLMO_CHECK_ARG(r.A && r.B && r.C, "vlmo_gemm_tn_multi: null operand in problem %d", q0 + q);
+            VLMO_CHECK_ARG(r.M > 0 && r.N1 >= 8 && r.N2 >= 8 && r.N1 % 8 == 0 && r.N2 % 8 == 0 && r.lda % 8 == 0 &&
+                               r.ldb % 8 == 0 && r.lda >= r.N1 && r.ldb >= r.N2 && r.ldc >= r.N2,
+                           "vlmo_gemm_tn_multi: bad shape in problem %d (M=%d N1=%d N2=%d)", q0 + q, r.M, r.N1, r.N2);
+            tiles_all += (long)((r.N1 + 255) / 256) * ((r.N2 + 255) / 256);
+            const int nk = (r.M + 63) / 64;
+            if (nk < min_nk) min_nk = nk;
+            flops += 2.0 * r.M * r.N1 * r.N2;
+        }
+        int splits = 1;
+        if (tiles_all < 192) {
+            splits = (int)(256 / tiles_all);
+            if (splits > min_nk / 8) splits = min_nk / 8;
+            if (splits < 1) splits = 1;
+        }
+        GemmTNMulti mp{};
+        mp.n = nq;
+        int t = 0;
+        for (int q = 0; q < nq; ++q) {
+            const VlmoTnProblem& r = probs[q0 + q];
+            const int tiles = ((r.N1 + 255) / 256) * ((r.N2 + 255) / 256);
+            const int nk = (r.M + 63) / 64;
+            int sp = splits > nk ? nk : splits;
+            const int per = (nk + sp - 1) / sp;
+            sp = (nk + per - 1) / per;
+            int mode = r.accumulate ? TN_ACCUM : TN_STORE;
+            if (sp > 1) {
+                mode = TN_ATOMIC;
+                if (!r.accumulate) {
+                    hipError_t rc = hipMemset2DAsync(r.C, (size_t)r.ldc * 4, 0, (size_t)r.N2 * 4, r.N1, stream);
+                    if (rc != hipSuccess) {
+                        vlmo_set_error("vlmo_gemm_tn_multi: memset failed: %s", hipGetErrorString(rc));
+                        return (int)rc;
+                    }
+                }
+            }
+            mp.p[q] = GemmTN{r.A, r.B, r.C, r.M, r.N1, r.N2, r.lda, r.ldb, r.ldc, per, tiles, r.alpha, nullptr, mode};
+            mp.t0[q] = t;
+            t += tiles * sp;
+        }
+        for (int q = nq; q <= MAX_TN_PROBS; ++q) mp.t0[q] = t;
+        ProfScope prof(73, flops, stream);
+        constexpr int LDS = 2 * 4 * 64 * 256;
+        if (dtype == VLMO_F16)
+            hipLaunchKernelGGL(gemm_tn_multi_kernel<f16>, dim3(t), dim3(512), LDS, stream, mp);
+        else
+            hipLaunchKernelGGL(gemm_tn_multi_kernel<bf16>, dim3(t), dim3(512), LDS, stream, mp);
+        VLMO_CHECK_LAUNCH("vlmo_gemm_tn_multi");
     }
     return 0;
 }

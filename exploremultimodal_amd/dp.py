@@ -216,9 +216,12 @@ class GradReducer:
     def release(self, group):
         self.release_all([group])
 
-    def release_all(self, groups):
+    def release_all(self, groups, ready_event=None):
         """The backward call that fed these groups has been enqueued.  Buckets whose last contribution of the step
-        this was are reduced now; neighbours in one block arena go out as ONE collective."""
+        this was are reduced now; neighbours in one block arena go out as ONE collective.  ready_event: native
+        event (hip.event_create) recorded when these gradients are complete (engine.StackFn: the whole stack's
+        backward is one call, so "everything enqueued so far on the current stream" would be the END of it)."""
+        self._ready_event = ready_event
         ready = []
         for g in groups:
             sb = self.sinks[self._key(g)]
@@ -239,12 +242,21 @@ class GradReducer:
                 self._launch_range(ready[i:j + 1])
             i = j + 1
 
+    def _comm_wait(self):
+        """Order the communication stream after the producers of the gradients about to be reduced."""
+        ev = getattr(self, '_ready_event', None)
+        if ev is not None:
+            from . import hip
+            hip.stream_wait_event(self.comm_stream, ev)
+        else:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+
     def _launch_range(self, sbs):
         """One pack / collective / unpack over the contiguous arena range of several ready buckets."""
         a = sbs[0].arena
         lo, hi = sbs[0].offset, sbs[-1].offset + sbs[-1].padded
         flat, comm = a.flat[lo:hi], a.comm[lo:hi]
-        self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._comm_wait()
         with torch.cuda.stream(self.comm_stream):
             if comm.data_ptr() != flat.data_ptr():
                 torch.mul(flat, 1.0 / self.world, out=comm)
@@ -261,7 +273,7 @@ class GradReducer:
         # everything on the communication stream (ordered after the block backward that just finished on the
         # current stream): the pack would otherwise sit in the dgrad chain's critical path 30 times per step
         if self.on_gpu:
-            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._comm_wait()
             ctxm = torch.cuda.stream(self.comm_stream)
         else:
             from contextlib import nullcontext

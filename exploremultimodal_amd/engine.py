@@ -11,6 +11,8 @@ reference's torch.cat([txt, img], dim=1) (vlmo.py:406) never materialises.
 The residual stream is fp32 (as under the reference's autocast), GEMM operands
 bf16 with fp32 accumulation, parameters fp32 masters with cached bf16 shadows.
 """
+import ctypes
+
 import torch
 
 from . import hip
@@ -197,6 +199,83 @@ class _Fork:
             self.main.wait_stream(self.side)
 
 
+def _fill_forward(D, meta, params, launches, lse_sizes, M, pb, pf, need_bwd, keep):
+    """Forward part of a VlmoBlockDesc: geometry, parameters (fp32 vectors, bf16 weight shadows) and the saved-
+    activation slabs at pb (bf16) / pf (fp32).  params in BlockFn's order; x / x2 are set by the caller."""
+    (g1, g2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b) = params[:11]
+    nexp = len(meta.expert_ranges)
+    pl, d, H, hid = meta.plan, meta.d, meta.heads, meta.hidden
+    sh = meta.shadows
+    qkv_bias = sh.qkv_bias(q_bias, v_bias)
+    D.M, D.d, D.hidden, D.heads = M, d, hid, H
+    D.n_experts = nexp
+    for i, (r0, n) in enumerate(meta.expert_ranges):
+        D.exp_row0[i], D.exp_rows[i] = r0, n
+    D.n_attn = len(launches)
+    md2 = M * d * 2
+    D.y1, D.qkv, D.ctx, D.zd1, D.y2 = pb, pb + md2, pb + 4 * md2, pb + 5 * md2, pb + 6 * md2
+    D.u, D.h, D.zd2 = pb + 7 * md2, pb + 11 * md2, pb + 15 * md2
+    D.x1 = pf
+    st = pf + M * d * 4
+    D.mean1, D.rstd1, D.mean2, D.rstd2 = st, st + 4 * M, st + 8 * M, st + 12 * M
+    off = st + 16 * M
+    for i, ((seg, nseq, ml), sz) in enumerate(zip(launches, lse_sizes)):
+        D.seg[i], D.nseq[i], D.maxlen[i] = seg.data_ptr(), nseq, ml
+        D.lse_stride[i] = ((ml + 31) // 32) * 32
+        D.lse[i] = off
+        off += sz * 4
+    D.keymask = hip._p(pl.keymask)
+    D.eps = meta.eps
+    D.drop_thresh, D.inv_keep = meta.drop
+    D.attn_drop_thresh, D.attn_inv_keep = meta.attn_drop
+    D.seed = meta.seed & 0xFFFFFFFFFFFFFFFF
+    D.rs1, D.rs2 = hip._p(meta.rs1), hip._p(meta.rs2)
+    D.row_index = pl.row_group.data_ptr() if meta.rs1 is not None else None
+    D.tile, D.need_bwd = meta.tile, int(need_bwd)
+    D.g1, D.g2, D.n1w, D.n1b, D.n2w, D.n2b = (t.data_ptr() for t in (g1, g2, n1w, n1b, n2w, n2b))
+    D.qkv_bias, D.proj_b = qkv_bias.data_ptr(), proj_b.data_ptr()
+    keep.append(qkv_bias)
+    w, wt = sh.get(qkv_w)
+    D.qkv_w, D.qkv_wT = w.data_ptr(), wt.data_ptr()
+    keep += [w, wt]
+    w, wt = sh.get(proj_w)
+    D.proj_w, D.proj_wT = w.data_ptr(), wt.data_ptr()
+    keep += [w, wt]
+    for i in range(nexp):
+        w1, b1, w2, b2 = params[11 + 4 * i: 15 + 4 * i]
+        a, at = sh.get(w1)
+        c, ct = sh.get(w2)
+        D.w1[i], D.w1T[i], D.w2[i], D.w2T[i] = a.data_ptr(), at.data_ptr(), c.data_ptr(), ct.data_ptr()
+        D.b1[i], D.b2[i] = b1.data_ptr(), b2.data_ptr()
+        keep += [a, at, c, ct]
+
+
+def _carve(flat, shapes):
+    out, off = [], 0
+    for shp in shapes:
+        n = 1
+        for s_ in shp:
+            n *= s_
+        out.append(flat[off:off + n].view(*shp))
+        off += n
+    return out
+
+
+def _fill_grads(D, flats, d, hid, nexp):
+    """Parameter-gradient pointers of a VlmoBlockDesc from flat fp32 storage (flats[0]: shared parameters,
+    flats[1 + e]: expert e) -> gradient tensors in BlockFn's parameter order."""
+    (dg1, dg2, dn1w, dn1b, dn2w, dn2b, dqkv_w, dproj_w, dproj_b, dqkv_b) = _carve(
+        flats[0], [(d,)] * 6 + [(3 * d, d), (d, d), (d,), (3 * d,)])
+    D.dg1, D.dg2, D.dn1w, D.dn1b, D.dn2w, D.dn2b = (t.data_ptr() for t in (dg1, dg2, dn1w, dn1b, dn2w, dn2b))
+    D.dqkv_w, D.dproj_w, D.dproj_b, D.dqkv_b = (t.data_ptr() for t in (dqkv_w, dproj_w, dproj_b, dqkv_b))
+    dexp = []
+    for i in range(nexp):
+        dw1, db1, dw2, db2 = _carve(flats[1 + i], [(hid, d), (hid,), (d, hid), (d,)])
+        D.dw1[i], D.db1[i], D.dw2[i], D.db2[i] = dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
+        dexp += [dw1, db1, dw2, db2]
+    return [dg1, dg2, dn1w, dn1b, dqkv_w, dqkv_b[:d], dqkv_b[2 * d:], dproj_w, dproj_b, dn2w, dn2b] + dexp
+
+
 class BlockFn(torch.autograd.Function):
     """One VLMo Block (vlmo.py:187-197) = norm1 -> qkv -> attention -> proj(+gamma_1, residual) -> norm2 ->
     expert FFN(+gamma_2, residual), forward and backward each ONE native call (vlmo_block_fwd / vlmo_block_bwd).
@@ -354,6 +433,182 @@ class BlockFn(torch.autograd.Function):
             sink.release_all(ctx.sink_groups)
             return (dx0, None) + (None,) * len(grads)
         return (dx0, None, *grads)
+
+
+WGRAD_BATCH = int(_os.environ.get('VLMO_WGRAD_BATCH', '2'))     # blocks per deferred weight-gradient launch
+TMP_SETS = int(_os.environ.get('VLMO_TMP_SETS', '4'))            # rotation depth of the backward temporaries
+USE_STACK = _os.environ.get('VLMO_STACK', '1') != '0'            # one native call per pass (else one per block)
+
+_PERSIST = {}
+
+
+def _persist(dev, tag, numel, dtype):
+    """Scratch that lives across passes (backward temporaries, column workspaces): keyed by the caller's stream,
+    because reuse is ordered by that stream (vlmo_stack_bwd joins its side stream before it returns)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, tag)
+    t = _PERSIST.get(key)
+    if t is None or t.numel() < numel or t.dtype != dtype:
+        t = _PERSIST[key] = torch.empty(numel, dtype=dtype, device=dev)
+    return t
+
+
+_EVENTS = {}
+
+
+def _ready_events(dev, n):
+    evs = _EVENTS.setdefault(dev, [])
+    while len(evs) < n:
+        evs.append(hip.event_create())
+    return evs[:n]
+
+
+class StackFn(torch.autograd.Function):
+    """All Blocks of one backbone pass (the loops at vlmo.py:402-411) as ONE native call per direction
+    (vlmo_stack_fwd / vlmo_stack_bwd).  metas: one BlockMeta per block, in forward order; params: the blocks'
+    parameter lists concatenated, each in BlockFn's order."""
+
+    @staticmethod
+    def forward(ctx, x, metas, *params):
+        nb = len(metas)
+        m0 = metas[0]
+        pl, d, H, hid = m0.plan, m0.d, m0.heads, m0.hidden
+        M, dev = x.shape[0], x.device
+        need_bwd = any(ctx.needs_input_grad)
+        x = x.contiguous()
+        md = M * d
+        # per block: one bf16 slab  y1 | qkv(3) | ctx | zd1 | y2 | u(4) | h(4) | zd2  (units of M*d) and one fp32
+        # slab  x1 | mean1 rstd1 mean2 rstd2 | lse...  ; the blocks' outputs x2 (= the next block's saved input)
+        lse_sizes, launches = [], []
+        for mt in metas:
+            ln = pl.attn_launches(mt.fused)
+            launches.append(ln)
+            lse_sizes.append([nseq * H * (((ml + 31) // 32) * 32) for _, nseq, ml in ln])
+        sf_n = [md + 4 * M + sum(ls) for ls in lse_sizes]
+        live = nb if need_bwd else 1        # without a backward every block reuses the first block's slabs
+        SB = torch.empty(live * 16 * md, dtype=torch.bfloat16, device=dev)
+        SF = torch.empty(sum(sf_n[:live]) if need_bwd else max(sf_n), dtype=torch.float32, device=dev)
+        X2 = torch.empty((nb if need_bwd else min(nb, 2), M, d), dtype=torch.float32, device=dev)
+        descs = (hip.BlockDesc * nb)()
+        keep = [SB, SF, X2, pl]
+        pofs, sf_off = 0, 0
+        xin = x.data_ptr()
+        spans = []
+        for i, mt in enumerate(metas):
+            nexp = len(mt.expert_ranges)
+            npar = 11 + 4 * nexp
+            bp = params[pofs:pofs + npar]
+            spans.append((pofs, npar))
+            pofs += npar
+            D = descs[i]
+            pb = SB.data_ptr() + (i * 16 * md * 2 if need_bwd else 0)
+            pf = SF.data_ptr() + (sf_off * 4 if need_bwd else 0)
+            sf_off += sf_n[i]
+            x2 = X2[i if need_bwd else i % 2]
+            _fill_forward(D, mt, bp, launches[i], lse_sizes[i], M, pb, pf, need_bwd, keep)
+            D.x, D.x2 = xin, x2.data_ptr()
+            xin = x2.data_ptr()
+        S = hip.StackDesc()
+        S.n_blocks = nb
+        S.blocks = ctypes.cast(descs, ctypes.POINTER(hip.BlockDesc))
+        hip.stack_fwd(S)
+        out = X2[(nb - 1) if need_bwd else (nb - 1) % 2]
+        if need_bwd:
+            ctx.metas, ctx.descs, ctx.keep, ctx.spans = metas, descs, keep, spans
+            ctx.save_for_backward(x, *params)
+            ctx.sink = GRAD_SINK
+            if ctx.sink is not None:
+                ctx.sink_groups = []
+                for (o, n_) in spans:
+                    bp = params[o:o + n_]
+                    groups = [tuple(bp[:11])] + [tuple(bp[11 + 4 * e: 15 + 4 * e]) for e in range((n_ - 11) // 4)]
+                    ctx.sink_groups.append(groups)
+                    for g_ in groups:
+                        ctx.sink.expect(g_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dxo):
+        metas, descs, spans = ctx.metas, ctx.descs, ctx.spans
+        x, *params = ctx.saved_tensors
+        nb = len(metas)
+        m0 = metas[0]
+        d, hid = m0.d, m0.hidden
+        M, dev = x.shape[0], x.device
+        md = M * d
+        f32 = torch.float32
+        dxo = dxo.contiguous()
+        sink = ctx.sink
+        shared_n = 6 * d + 3 * d * d + d * d + d + 3 * d
+        exp_n = 2 * hid * d + hid + d
+        nsets = max(1, min(TMP_SETS, nb))
+        batch = max(1, min(WGRAD_BATCH, nsets - 1)) if nb > nsets else max(1, WGRAD_BATCH)
+        # persistent scratch: backward temporaries (dz2 | du(4) | dy2=dctx | dz1 | dqkv(3) | dy1 bf16) and column
+        # workspaces, one set per block in flight; dx1 and the dx ping-pong
+        tb = _persist(dev, 'tb', nsets * 11 * md, torch.bfloat16)
+        slot = hip.lib().vlmo_reduce_ws_bytes(2 * d)
+        ws_n = 5 * slot // 4
+        ws = _persist(dev, 'ws', nsets * ws_n, f32)
+        dxs = _persist(dev, 'dx', 3 * md, f32)
+        dx_in = torch.empty((M, d), dtype=f32, device=dev)
+        if sink is None:
+            tot = sum(shared_n + ((n_ - 11) // 4) * exp_n for (_, n_) in spans)
+            whole = torch.zeros(tot, dtype=f32, device=dev)       # ONE memset for every parameter gradient of the pass
+        grads_all = [None] * len(params)
+        goff = 0
+        for k in range(nb):                 # backward order: k-th processed block is i = nb-1-k
+            i = nb - 1 - k
+            D = descs[i]
+            o, n_ = spans[i]
+            nexp = (n_ - 11) // 4
+            if sink is not None:
+                akey, aroom = id(params[o]), shared_n + 3 * exp_n
+                groups = ctx.sink_groups[i]
+                flats = [sink.acquire(groups[0], shared_n, dev, akey, aroom)] + \
+                        [sink.acquire(g_, exp_n, dev, akey, aroom) for g_ in groups[1:]]
+            else:
+                flats = [whole[goff:goff + shared_n]]
+                goff += shared_n
+                for e in range(nexp):
+                    flats.append(whole[goff:goff + exp_n])
+                    goff += exp_n
+            grads = _fill_grads(D, flats, d, hid, nexp)
+            grads_all[o:o + n_] = grads
+            st_ = k % nsets
+            pb = tb.data_ptr() + st_ * 11 * md * 2
+            md2 = md * 2
+            D.dz2, D.du, D.dy2, D.dz1, D.dqkv, D.dy1 = pb, pb + md2, pb + 5 * md2, pb + 6 * md2, pb + 7 * md2, pb + 10 * md2
+            D.dctx = D.dy2
+            D.ws_main, D.ws_bytes = ws.data_ptr() + st_ * ws_n * 4, ws_n * 4
+            D.ws_side, D.side_stream, D.ws_tn, D.ws_tn_bytes = None, None, None, 0
+            D.dx1 = dxs.data_ptr() + 2 * md * 4
+            D.dx2 = dxo.data_ptr() if k == 0 else dxs.data_ptr() + ((k - 1) % 2) * md * 4
+            D.dx0 = dx_in.data_ptr() if k == nb - 1 else dxs.data_ptr() + (k % 2) * md * 4
+        S = hip.StackDesc()
+        S.n_blocks, S.wgrad_batch, S.n_tmp_sets = nb, batch, nsets
+        S.blocks = ctypes.cast(descs, ctypes.POINTER(hip.BlockDesc))
+        side = _side_stream(dev) if OVERLAP_WGRAD else None
+        S.side_stream = side.cuda_stream if side is not None else None
+        evs = None
+        if sink is not None and side is not None:
+            evs = _ready_events(dev, nb)
+            arr = (ctypes.c_void_p * nb)(*evs)
+            S.grad_ready = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        hip.stack_bwd(S)
+        ctx.descs = ctx.keep = None
+        if sink is not None:
+            for k in range(nb):
+                i = nb - 1 - k
+                o, n_ = spans[i]
+                for p_, g_ in zip(params[o:o + n_], grads_all[o:o + n_]):
+                    if p_.requires_grad:
+                        if p_.grad is None:
+                            p_.grad = g_
+                        elif p_.grad.data_ptr() != g_.data_ptr():
+                            raise RuntimeError('a parameter of a data-parallel block already holds a foreign .grad; '
+                                               'use zero_grad(set_to_none=True)')
+                sink.release_all(ctx.sink_groups[i], ready_event=evs[i] if evs is not None else None)
+            return (dx_in, None) + (None,) * len(params)
+        return (dx_in, None, *grads_all)
 
 
 class FinalNormFn(torch.autograd.Function):

@@ -56,6 +56,24 @@ class BlockDesc(ctypes.Structure):
            ('side_stream', _fp)])
 
 
+class StackDesc(ctypes.Structure):
+    """Mirror of VlmoStackDesc (include/vlmo_hip.h)."""
+    _fields_ = [('n_blocks', _i32), ('wgrad_batch', _i32), ('n_tmp_sets', _i32), ('pad_', _i32),
+                ('blocks', ctypes.POINTER(BlockDesc)), ('side_stream', _vp), ('grad_ready', ctypes.POINTER(_vp))]
+
+
+class TnProblem(ctypes.Structure):
+    """Mirror of VlmoTnProblem."""
+    _fields_ = [('A', _vp), ('B', _vp), ('C', _vp), ('lda', _i32), ('ldb', _i32), ('ldc', _i32),
+                ('M', _i32), ('N1', _i32), ('N2', _i32), ('alpha', _f32), ('accumulate', _i32)]
+
+
+class ColJob(ctypes.Structure):
+    """Mirror of VlmoColJob."""
+    _fields_ = [('kind', _i32), ('ld', _i32), ('src', _vp), ('rows', _i32), ('ncols', _i32),
+                ('out', _vp * 4), ('n0', _i32), ('pad_', _i32)]
+
+
 _SIGS = {
     'vlmo_gemm_nt': [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32,
                      ctypes.POINTER(Epilogue), _vp],
@@ -85,6 +103,13 @@ _SIGS = {
     'vlmo_argmax_reduce': [_vp, _i32, _vp, _i32, _vp],
     'vlmo_block_fwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_block_bwd': [ctypes.POINTER(BlockDesc), _vp],
+    'vlmo_stack_fwd': [ctypes.POINTER(StackDesc), _vp],
+    'vlmo_stack_bwd': [ctypes.POINTER(StackDesc), _vp],
+    'vlmo_gemm_tn_multi': [_i32, ctypes.POINTER(TnProblem), _i32, _vp],
+    'vlmo_colwork_multi': [_i32, ctypes.POINTER(ColJob), _i32, _vp],
+    'vlmo_event_create': [ctypes.POINTER(ctypes.c_void_p)],
+    'vlmo_event_destroy': [_vp],
+    'vlmo_stream_wait_event': [_vp, _vp],
     'vlmo_profile_start': [_i32],
     'vlmo_gemm_nt_grouped': [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     'vlmo_mt_grad_norm': [ctypes.c_void_p, _f32, _f32, _vp, _vp, _vp],
@@ -354,6 +379,46 @@ def argmax_reduce(partial, nchunk, ids, M):
     _check(lib().vlmo_argmax_reduce(_p(partial), nchunk, _p(ids), M, _stream()), 'vlmo_argmax_reduce')
 
 
+def gemm_tn_multi(problems, dtype=BF16):
+    """problems: [(A, B, C, M, N1, N2, accumulate)] with A [M, >=N1], B [M, >=N2] bf16/f16 and C [N1, >=N2] fp32."""
+    n = len(problems)
+    arr = (TnProblem * n)()
+    for i, (A, B, C, M, N1, N2, acc) in enumerate(problems):
+        arr[i] = TnProblem(_p(A), _p(B), _p(C), A.stride(0), B.stride(0), C.stride(0), M, N1, N2, 1.0, int(acc))
+    _check(lib().vlmo_gemm_tn_multi(dtype, arr, n, _stream()), 'vlmo_gemm_tn_multi')
+
+
+def colwork_multi(jobs, dtype=BF16):
+    """jobs: [(kind, src, rows, ncols, outs, n0)]; kind 0 = fold fp32 partial rows src [rows, ncols],
+    kind 1 = column sums of the bf16/f16 matrix src [rows, ld]."""
+    n = len(jobs)
+    arr = (ColJob * n)()
+    for i, (kind, src, rows, ncols, outs, n0) in enumerate(jobs):
+        o = (ctypes.c_void_p * 4)(*[_p(t) for t in (list(outs) + [None] * 4)[:4]])
+        arr[i] = ColJob(kind, src.stride(0), _p(src), rows, ncols, o, n0, 0)
+    _check(lib().vlmo_colwork_multi(dtype, arr, n, _stream()), 'vlmo_colwork_multi')
+
+
+def event_create():
+    out = ctypes.c_void_p()
+    _check(lib().vlmo_event_create(ctypes.byref(out)), 'vlmo_event_create')
+    return out.value
+
+
+def stream_wait_event(stream, ev):
+    """stream: torch stream (or raw handle); ev: handle from event_create()."""
+    raw = stream.cuda_stream if hasattr(stream, 'cuda_stream') else stream
+    _check(lib().vlmo_stream_wait_event(raw, ev), 'vlmo_stream_wait_event')
+
+
+def stack_fwd(sdesc):
+    _check(lib().vlmo_stack_fwd(ctypes.byref(sdesc), _stream()), 'vlmo_stack_fwd')
+
+
+def stack_bwd(sdesc):
+    _check(lib().vlmo_stack_bwd(ctypes.byref(sdesc), _stream()), 'vlmo_stack_bwd')
+
+
 def block_fwd(desc):
     _check(lib().vlmo_block_fwd(ctypes.byref(desc), _stream()), 'vlmo_block_fwd')
 
@@ -414,6 +479,8 @@ def profile_stop():
         if ln[t]:
             if t in (64, 72):
                 name = 'gemm_tn_kernel<%s>' % ('256x256' if t == 72 else '128x128')
+            elif t == 73:
+                name = 'gemm_tn_multi_kernel<256x256>'
             elif t >= 32:
                 name = f'conv_nt_kernel<{names.get(t - 32, t - 32)}>'
             else:

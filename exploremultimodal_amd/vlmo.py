@@ -134,9 +134,10 @@ class Block(nn.Module):
             ps += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
         return ps
 
-    def run(self, x, plan, routes, ranges, fused, shadows, seed, drop_scales=None):
-        """x: packed fp32 [M, d]; routes/ranges: experts and their row ranges; drop_scales: this block's
-        drop-path scales [branch, stream, B] when the caller drew them for all blocks at once."""
+    def meta(self, x, plan, routes, ranges, fused, shadows, seed, drop_scales=None):
+        """engine.BlockMeta + parameter list of one call of this block.  routes/ranges: experts and their row
+        ranges; drop_scales: this block's drop-path scales [branch, stream, B] when the caller drew them for all
+        blocks at once."""
         rs1 = rs2 = None
         if drop_scales is not None:
             if self.drop_path_rate > 0.0:
@@ -154,7 +155,14 @@ class Block(nn.Module):
         meta = engine.BlockMeta(plan, self.num_heads, self.dim, self.mlp_hidden_dim, fused, ranges, self.training,
                                 self.drop, self.attn.attn_drop, rs1, rs2, seed, eps=self.norm1.eps)
         meta.shadows = shadows
-        return engine.BlockFn.apply(x, meta, *self._params(routes))
+        return meta, self._params(routes)
+
+    def run(self, x, plan, routes, ranges, fused, shadows, seed, drop_scales=None):
+        """x: packed fp32 [M, d] -> this block's output (one native call per direction)."""
+        meta, params = self.meta(x, plan, routes, ranges, fused, shadows, seed, drop_scales)
+        if engine.USE_STACK:
+            return engine.StackFn.apply(x, [meta], *params)
+        return engine.BlockFn.apply(x, meta, *params)
 
     def forward(self, x, mask=None, route='vl'):
         """Reference signature (vlmo.py:187): x [B, N, d] -> (x, attn=None)."""
@@ -321,6 +329,15 @@ class VLMO(nn.Module):
             # fused / single-stream blocks: both streams of a sample share the draw of the stream that exists
             u = torch.where(sd.unsqueeze(-1) > 0, u[:, :, first:first + 1].expand_as(u), u)
             scales = (u < kd).to(torch.float32) / kd
+        if engine.USE_STACK and todo:
+            # the whole stack in ONE native call per direction (engine.StackFn)
+            metas, params = [], []
+            for n, (i, routes, ranges, fused) in enumerate(todo):
+                mt, ps = self.blocks[i].meta(x, plan, routes, ranges, fused, self._shadows, seed + 1000 * (i + 1),
+                                             drop_scales=scales[n] if scales is not None else None)
+                metas.append(mt)
+                params += ps
+            return engine.StackFn.apply(x, metas, *params)
         for n, (i, routes, ranges, fused) in enumerate(todo):
             x = self.blocks[i].run(x, plan, routes, ranges, fused, self._shadows, seed + 1000 * (i + 1),
                                    drop_scales=scales[n] if scales is not None else None)

@@ -93,6 +93,21 @@ int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, floa
                  int M, int N1, int N2, float alpha, int splits, float* ws, int64_t ws_bytes,
                  hipStream_t stream);
 
+/* Several weight gradients C_q[N1,N2] (+)= alpha * A_q[M,N1]^T . B_q[M,N2] in ONE launch of 256x256 tiles:
+ * the qkv / proj / fc1 / fc2 gradients of one or two transformer blocks (autograd of vlmo.py:76-78,96,195-196)
+ * together fill the chip without splitting the token dimension, so there are no partial slabs and no
+ * reduction pass.  accumulate != 0: C += ..., else C = ...  No workspace. */
+typedef struct VlmoTnProblem {
+    const void* A;
+    const void* B;
+    float* C;
+    int32_t lda, ldb, ldc;
+    int32_t M, N1, N2;
+    float alpha;
+    int32_t accumulate;
+} VlmoTnProblem;
+int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, hipStream_t stream);
+
 /* LayerNorm over the last dim (eps = 1e-12 in VLMo: vlmo_module.py:21-23; vlmo.py:188,192,413).
  * x fp32 [M,d] -> y (bf16, or fp32 when out_f32) at row rowmap[m] (or m), + mean/rstd [M]. */
 int vlmo_ln_fwd(const float* x, const float* w, const float* b, void* y, int out_f32,
@@ -141,6 +156,19 @@ int vlmo_resid_bwd(const float* dx, const void* zd, const float* gamma, const fl
 /* out[c] += sum_m x[m, c]  (bias gradients), x is bf16/f16 [M, ld]. */
 int vlmo_colsum(int dtype, const void* x, int ld, float* out, int M, int N, float* ws,
                 int64_t ws_bytes, hipStream_t stream);
+
+/* Column work of several producers in ONE launch (the bias / layer-scale / LayerNorm-weight gradients of one or
+ * two transformer blocks):  kind 0 folds fp32 partial rows ws[rows, ncols] (written by vlmo_ln_bwd /
+ * vlmo_ln_resid_bwd / vlmo_resid_bwd with defer), kind 1 sums the columns of a bf16/f16 matrix x[rows, ld].
+ * Column c goes to out[c / n0][c % n0] += sum (out[k] may be NULL). */
+typedef struct VlmoColJob {
+    int32_t kind, ld;
+    const void* src;
+    int32_t rows, ncols;
+    float* out[4];
+    int32_t n0, pad_;
+} VlmoColJob;
+int vlmo_colwork_multi(int dtype, const VlmoColJob* jobs, int n, hipStream_t stream);
 
 /* fp32 -> bf16/f16 weight shadow copies: dst = cast(src), dstT = cast(src)^T (either may be NULL). */
 int vlmo_cast_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT,
@@ -226,7 +254,7 @@ int vlmo_side_stream_create(int low_priority, const uint32_t* cu_mask, int cu_ma
  * beside the input-gradient chain and joins before returning control of the buffers. */
 typedef struct VlmoBlockDesc {
     int32_t M, d, hidden, heads;
-    int32_t n_experts, exp_row0[2], exp_rows[2];
+    int32_t n_experts, exp_row0[2], exp_rows[2];   /* 1..2 experts */
     int32_t n_attn, nseq[2], maxlen[2], lse_stride[2];
     const int32_t* seg[2];
     const int32_t* keymask;
@@ -262,6 +290,31 @@ typedef struct VlmoBlockDesc {
 } VlmoBlockDesc;
 int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t stream);
 int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t stream);
+
+/* ---- all blocks of one backbone pass in ONE call per direction (the loops at vlmo.py:402-411) -------------
+ * blocks[] are in forward order; block i's x2 is block i+1's x.  vlmo_stack_fwd = vlmo_block_fwd per block.
+ * vlmo_stack_bwd runs the activation-gradient chains of all blocks back to back on `stream` and defers the
+ * parameter-gradient work (weight-gradient GEMMs, bias / layer-scale / LayerNorm column sums) to
+ * `side_stream` in batches of `wgrad_batch` blocks, one vlmo_gemm_tn_multi + one vlmo_colwork_multi launch
+ * per batch (parameter gradients are ACCUMULATED: zero or pre-load them).  Because that work runs later than
+ * the block's own chain, the caller gives the k-th block in backward order its own backward temporaries
+ * (dz2, du, dz1, dqkv) and column workspace ws_main (>= (3 + n_experts) * vlmo_reduce_ws_bytes(2*d) bytes),
+ * rotating over n_tmp_sets > wgrad_batch sets (set k % n_tmp_sets); the call waits for a set's deferred readers
+ * before reusing it and joins the side stream before it returns control of the buffers.  ws_side, ws_tn and
+ * the blocks' own side_stream field are ignored.  grad_ready (optional, [n_blocks] hipEvent_t handles from
+ * vlmo_event_create): event i is recorded when block i's parameter gradients are complete, so a gradient
+ * all-reduce on another stream can start per block (vlmo_stream_wait_event). */
+typedef struct VlmoStackDesc {
+    int32_t n_blocks, wgrad_batch, n_tmp_sets, pad_;
+    const VlmoBlockDesc* blocks;
+    hipStream_t side_stream;
+    void* const* grad_ready;
+} VlmoStackDesc;
+int vlmo_stack_fwd(const VlmoStackDesc* s, hipStream_t stream);
+int vlmo_stack_bwd(const VlmoStackDesc* s, hipStream_t stream);
+int vlmo_event_create(void** out);
+int vlmo_event_destroy(void* ev);
+int vlmo_stream_wait_event(hipStream_t stream, void* ev);
 
 /* ---- dall_e dVAE encoder (dall_e/encoder.py:49-133), fp16 NHWC activations [B*H*W, C] ---- */
 

@@ -453,3 +453,72 @@ def test_ln_resid_bwd_equals_ln_bwd_then_resid_bwd(drop):
     assert torch.equal(dx0, dx1) and torch.equal(dz0, dz1)
     for a, b_ in ((dw0, dw1), (db0, db1), (dg0, dg1), (dpb0, dpb1)):
         torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_tn_multi_exact_integers():
+    """vlmo_gemm_tn_multi: several weight-gradient problems of different shapes in ONE launch, exact small-integer
+    data.  Covers the no-split path (>= 192 tiles: in-place store / accumulate), the split path (few tiles: fp32
+    atomics, incl. the memset of a non-accumulating output), edge tiles (N not a multiple of 256), a token count that
+    is not a multiple of 64, and leading dimensions larger than the used columns."""
+    g = torch.Generator().manual_seed(11)
+
+    def prob(M, N1, N2, lda_extra=0, ldb_extra=0, acc=True):
+        A = torch.randint(-2, 3, (M, N1 + lda_extra), generator=g).float()
+        B = torch.randint(-2, 3, (M, N2 + ldb_extra), generator=g).float()
+        B[:, 0] += torch.arange(M).float() % 3
+        C0 = torch.randint(-4, 5, (N1, N2), generator=g).float()
+        ref = A[:, :N1].t() @ B[:, :N2] + (C0 if acc else 0)
+        return (A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), C0.to(DEV).clone(), M, N1, N2, acc), ref
+
+    # few tiles -> token dimension split, atomics
+    small = [prob(700, 256, 512), prob(333, 96, 264, acc=False), prob(1000, 512, 256, lda_extra=64, ldb_extra=8)]
+    hip.gemm_tn_multi([p for p, _ in small])
+    torch.cuda.synchronize()
+    for (p, ref) in small:
+        assert torch.equal(p[2].cpu(), ref), (p[2].cpu() - ref).abs().max()
+    # >= 192 tiles together -> every tile owned by one workgroup, in-place accumulate / store
+    big = [prob(300, 768, 3072), prob(200, 3072, 768, acc=False), prob(130, 768, 768), prob(257, 2304, 768),
+           prob(64, 1000, 264, acc=False)]
+    hip.gemm_tn_multi([p for p, _ in big])
+    torch.cuda.synchronize()
+    for (p, ref) in big:
+        assert torch.equal(p[2].cpu(), ref), (p[2].cpu() - ref).abs().max()
+
+
+def test_gemm_tn_multi_more_than_16_problems():
+    g = torch.Generator().manual_seed(5)
+    probs, refs = [], []
+    for i in range(19):
+        M, N1, N2 = 64 + 8 * i, 256, 264
+        A = torch.randint(-2, 3, (M, N1), generator=g).float()
+        B = torch.randint(-2, 3, (M, N2), generator=g).float()
+        probs.append((A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), torch.zeros(N1, N2, device=DEV), M, N1, N2, True))
+        refs.append(A.t() @ B)
+    hip.gemm_tn_multi(probs)
+    torch.cuda.synchronize()
+    for p, r in zip(probs, refs):
+        assert torch.equal(p[2].cpu(), r)
+
+
+def test_colwork_multi():
+    """vlmo_colwork_multi: partial-row folds into up to four outputs and bf16 column sums, batched in one launch."""
+    g = torch.Generator().manual_seed(3)
+    d = 192
+    ws = torch.randn(300, 4 * d, generator=g).to(DEV)
+    o = [torch.randn(d, generator=g).to(DEV) for _ in range(4)]
+    o0 = [t.clone() for t in o]
+    ws2 = torch.randn(40, 2 * d, generator=g).to(DEV)
+    p, q = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    x = (torch.randn(5000, 520, generator=g)).to(DEV).bfloat16()
+    cs = torch.zeros(512, device=DEV)
+    x2 = (torch.randn(100, 64, generator=g)).to(DEV).bfloat16()
+    cs2 = torch.ones(64, device=DEV)
+    hip.colwork_multi([(0, ws, 300, 4 * d, o, d), (1, x, 5000, 512, [cs], 512), (0, ws2, 40, 2 * d, [p, None], d),
+                       (1, x2, 100, 64, [cs2], 64)])
+    torch.cuda.synchronize()
+    for k in range(4):
+        _close(o[k], o0[k] + ws[:, k * d:(k + 1) * d].sum(0), 1e-5, 1e-4, f'fold out{k}')
+    _close(p, ws2[:, :d].sum(0), 1e-5, 1e-4, 'fold with a NULL output')
+    assert torch.equal(q, torch.zeros_like(q))
+    _close(cs, x[:, :512].float().sum(0), 1e-5, 1e-3, 'colsum')
+    _close(cs2, 1 + x2.float().sum(0), 1e-5, 1e-3, 'colsum small')
