@@ -155,6 +155,17 @@ __device__ __forceinline__ f32x4 epilogue_ext(const GemmNT& p, int gmb, int rowc
     }
 }
 
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const void*)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 // bijective XCD-chunked remap: workgroups that share an XCD (bid % 8 equal)
 // get a contiguous range of logical tile ids, so the A row-panel re-reads of
 // neighbouring column tiles hit that XCD's L2.
@@ -191,9 +202,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     for (int q = 1; q < MAX_GROUPS; ++q)
         if (q < gp.ngroups && lid_all >= gp.t0[q]) gi = q;
     gi = __builtin_amdgcn_readfirstlane(gi);
-    const GemmNT& p = gp.g[gi];
+    // the chosen problem, copied into SGPRs ONCE (see uniform_i): a dynamically indexed kernarg struct is
+    // otherwise re-read with s_load + s_waitcnt at every use (115 scalar loads in the fc1 epilogue before this)
+    const GemmNT& gq = gp.g[gi];
+    GemmNT p;
+    p.A = uniform_ptr(gq.A), p.B = uniform_ptr(gq.B), p.zero = uniform_ptr(gq.zero);
+    p.M = uniform_i(gq.M), p.N = uniform_i(gq.N), p.K = uniform_i(gq.K), p.lda = uniform_i(gq.lda), p.ldb = uniform_i(gq.ldb);
+    p.cH = uniform_i(gq.cH), p.cW = uniform_i(gq.cW), p.cCin = uniform_i(gq.cCin), p.ckw = uniform_i(gq.ckw);
+    p.group_m = uniform_i(gq.group_m);
+    p.e.out = (void*)uniform_ptr(gq.e.out), p.e.out2 = (void*)uniform_ptr(gq.e.out2);
+    p.e.bias = (const float*)uniform_ptr(gq.e.bias), p.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
+    p.e.resid = (const float*)uniform_ptr(gq.e.resid), p.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
+    p.e.row_index = (const int32_t*)uniform_ptr(gq.e.row_index), p.e.aux = uniform_ptr(gq.e.aux);
+    p.e.ldo = uniform_i(gq.e.ldo), p.e.ld2 = uniform_i(gq.e.ld2), p.e.relu = uniform_i(gq.e.relu);
+    p.e.drop_thresh = (uint32_t)uniform_i((int)gq.e.drop_thresh);
+    p.e.inv_keep = uniform_f(gq.e.inv_keep), p.e.beta = uniform_f(gq.e.beta);
+    p.e.seed = (uint64_t)uniform_ptr((const void*)gq.e.seed);
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int lid = lid_all - gp.t0[gi];
+    const int lid = lid_all - uniform_i(gp.t0[gi]);
     // grouped order: the ~64 tiles an XCD works on at once form a compact group_m x (64/group_m)
     // block, so their A row-panels AND B column-panels together fit the XCD's 4 MiB L2
     const int gm_ = p.group_m > 0 ? p.group_m : 1;
@@ -440,6 +466,9 @@ struct GemmTN {
 };
 enum { TN_ATOMIC = 0, TN_ACCUM = 1, TN_STORE = 2 };
 
+#ifndef TN_PREFETCH_DIST
+#define TN_PREFETCH_DIST 0
+#endif
 // dual-use 256-byte-row image: chunk swizzle serving the transposed reads
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -567,7 +596,27 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
+        // L2 prefetch: both operands are activations streamed ONCE from HBM (a K-tile of this workgroup is 512
+        // lines of 128 B), and the two-buffer ring keeps one K-tile (64 KB per CU) in flight, which covers an L2
+        // hit but not an HBM miss.  Every lane touches one line of K-tile kt + PD with a 4-byte LDS-DMA into a
+        // dummy LDS area (no VGPR destination: nothing to keep live); it is issued right after the real DMA
+        // of the iteration, so the counted `vmcnt(1)` below still retires every real DMA (loads return in order).
+        constexpr int PD = TN_PREFETCH_DIST;
+        char* pf_dst = smem + 2 * STAGE + wave * 256;
+        const int pf_idx = wave * 64 + lane;            // 0..511 with NW == 8
+        const int pf_op = (pf_idx >> 8) & 1, pf_row = (pf_idx >> 2) & 63, pf_seg = pf_idx & 3;
+        const T* pf_base = pf_op ? (const T*)p.B + min(n2_0 + pf_seg * 64, p.N2 - 8)
+                                 : (const T*)p.A + min(n1_0 + pf_seg * 64, p.N1 - 8);
+        const int pf_ld = pf_op ? p.ldb : p.lda;
+        auto prefetch = [&](int kt) {
+            const int gr = min(kt * 64 + pf_row, p.M - 1);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pf_base + (size_t)gr * pf_ld), LDS_PTR(pf_dst), 4, 0, 0);
+        };
+        const bool pf_on = PD > 0 && NW == 8 && BM == 256 && BN == 256;
         stage(0, kt0);
+        if (pf_on)
+            for (int q = 1; q < PD; ++q)
+                if (kt0 + q < kt1) prefetch(kt0 + q);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) bar();
@@ -578,14 +627,22 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             read_step(cur, kt, 1, af[1], bf[1]);
             bar();
             if (more) stage((kt - kt0 + 1) & 1, kt + 1);
+            const bool pf = pf_on && kt + PD < kt1;
+            if (pf) prefetch(kt + PD);
             mfma_half();
             bar();
             read_step(cur, kt, 2, af[0], bf[0]);
             read_step(cur, kt, 3, af[1], bf[1]);
-            if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more && wm == 1) {
+                if (pf) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             bar();
             mfma_half();
-            if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more && wm == 0) {
+                if (pf) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             bar();
         }
         if (wm == 0) bar();
@@ -656,7 +713,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti
     for (int q = 1; q < MAX_TN_PROBS; ++q)
         if (q < mp.n && lid_all >= mp.t0[q]) gi = q;
     gi = __builtin_amdgcn_readfirstlane(gi);
-    gemm_tn_body<T, 256, 256, 2, 4, true>(mp.p[gi], lid_all - mp.t0[gi]);
+    // copy the chosen problem into SGPRs ONCE: a dynamically indexed kernarg struct is otherwise re-read with
+    // s_load + s_waitcnt at every use inside the K loop (908 scalar loads in the first build of this kernel)
+    const GemmTN& q = mp.p[gi];
+    GemmTN p;
+    p.A = uniform_ptr(q.A), p.B = uniform_ptr(q.B), p.C = (float*)uniform_ptr(q.C);
+    p.M = __builtin_amdgcn_readfirstlane(q.M), p.N1 = __builtin_amdgcn_readfirstlane(q.N1);
+    p.N2 = __builtin_amdgcn_readfirstlane(q.N2), p.lda = __builtin_amdgcn_readfirstlane(q.lda);
+    p.ldb = __builtin_amdgcn_readfirstlane(q.ldb), p.ldc = __builtin_amdgcn_readfirstlane(q.ldc);
+    p.kt_per_split = __builtin_amdgcn_readfirstlane(q.kt_per_split), p.tiles = __builtin_amdgcn_readfirstlane(q.tiles);
+    p.alpha = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.alpha)));
+    p.slab = nullptr;
+    p.mode = __builtin_amdgcn_readfirstlane(q.mode);
+    gemm_tn_body<T, 256, 256, 2, 4, true>(p, lid_all - __builtin_amdgcn_readfirstlane(mp.t0[gi]));
 }
 
 // C[r, c] += alpha * sum_s slab[s, r, c]   (one float4 per thread)
@@ -928,7 +997,7 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     dim3 grid(pl.tiles * pl.splits);
     ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
     if (pl.big) {
-        constexpr int LDS = 2 * 4 * 64 * 256;
+        constexpr int LDS = 2 * 4 * 64 * 256 + 2048;
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -963,7 +1032,7 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn_multi: dtype must be bf16 or f16");
     static bool attr = false;
     if (!attr) {
-        constexpr int LDS = 2 * 4 * 64 * 256;
+        constexpr int LDS = 2 * 4 * 64 * 256 + 2048;
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
@@ -990,6 +1059,11 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
             if (splits > min_nk / 8) splits = min_nk / 8;
             if (splits < 1) splits = 1;
         }
+        static const int force_splits = [] {
+            const char* sv = getenv("VLMO_TN_SPLITS");      // measurement aid
+            return sv ? atoi(sv) : 0;
+        }();
+        if (force_splits > 0) splits = force_splits;
         GemmTNMulti mp{};
         mp.n = nq;
         int t = 0;
@@ -1017,7 +1091,7 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         }
         for (int q = nq; q <= MAX_TN_PROBS; ++q) mp.t0[q] = t;
         ProfScope prof(73, flops, stream);
-        constexpr int LDS = 2 * 4 * 64 * 256;
+        constexpr int LDS = 2 * 4 * 64 * 256 + 2048;
         if (dtype == VLMO_F16)
             hipLaunchKernelGGL(gemm_tn_multi_kernel<f16>, dim3(t), dim3(512), LDS, stream, mp);
         else

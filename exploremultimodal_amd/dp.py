@@ -84,6 +84,7 @@ class _SinkBucket:
                 self.padded, dtype=comm_dtype, device=device)
         self.expected = 0       # backward calls still to come in this step
         self.fresh = True       # zero before the first accumulation of the step
+        self.reduced = False    # a collective has been issued for this step's contents
         self.work = None
         self.shard = None
 
@@ -141,9 +142,13 @@ class GradReducer:
     def sync_params(self, module):
         """rank 0's parameters and buffers everywhere (what DDP does at wrap time)."""
         with torch.no_grad():
-            for t in list(module.parameters()) + list(module.buffers()):
+            ts = list(module.parameters()) + list(module.buffers())
+            for t in ts:
                 dist.broadcast(t.data, src=dist.get_global_rank(self.pg, 0) if self.pg is not dist.group.WORLD else 0,
                                group=self.pg)
+            # the broadcast wrote through .data: bump the version counters so that bf16 weight shadows cached by a
+            # forward that ran before the reducer was built are re-cast (engine.ShadowCache keys on _version)
+            torch.autograd.graph.increment_version(ts)
 
     def bytes_per_step(self):
         el = 2 if self.comm_dtype in (torch.bfloat16, torch.float16) else 4
@@ -169,6 +174,23 @@ class GradReducer:
             b.used = [(p in used) and (id(p) not in self._sink_params) for p in b.params]
             b.expected = b.pending = sum(b.used)
             b.work, b.launched = None, False
+        # Engine sinks: forward() counted one expected backward call per grad-enabled block call (expect()), but a
+        # pass whose output does not reach `loss` (a non-finite task loss dropped from the sum as in
+        # train/pretrain/multimodal.py:281-284, an objective that returned python 0.) never runs its backward.
+        # The graph says which engine nodes WILL run: count those instead, so that a bucket is reduced after its
+        # last real contribution and never left holding local, un-averaged gradients.
+        counts = {}
+        for fn in seen:
+            groups = getattr(fn, 'sink_groups', None)
+            if groups is None or getattr(fn, 'sink', None) is not self:
+                continue
+            flat = groups if (groups and isinstance(groups[0], tuple)) else [g_ for blk in groups for g_ in blk]
+            for g_ in flat:
+                k = self._key(g_)
+                counts[k] = counts.get(k, 0) + 1
+        for k, sb in self.sinks.items():
+            sb.expected = counts.get(k, 0)
+        self._pending_expect = {k: c for k, c in counts.items() if k not in self.sinks}
         self._armed = True
 
     # ---- engine sink protocol (called from engine.BlockFn) -------------------------------------------
@@ -207,7 +229,7 @@ class GradReducer:
             sb.work.wait()
             if self.on_gpu:
                 torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-            sb.work, sb.fresh, sb.unpacked = None, True, False
+            sb.work, sb.fresh, sb.unpacked, sb.reduced = None, True, False, False
         if sb.fresh:
             sb.flat.zero_()
             sb.fresh = False
@@ -267,9 +289,10 @@ class GradReducer:
             if comm.data_ptr() != flat.data_ptr():
                 flat.copy_(comm)
         for sb in sbs:
-            sb.work, sb.unpacked = work, True
+            sb.work, sb.unpacked, sb.reduced = work, True, True
 
     def _launch_sink(self, sb):
+        sb.reduced = True
         # everything on the communication stream (ordered after the block backward that just finished on the
         # current stream): the pack would otherwise sit in the dgrad chain's critical path 30 times per step
         if self.on_gpu:
@@ -350,8 +373,12 @@ class GradReducer:
             b.flat.copy_(b.comm)                     # bf16 -> fp32 unpack (already averaged)
         b.unpacked = True
 
-    def finish(self):
-        """Wait for every bucket, scale by 1/world, hand the averaged gradients back."""
+    def finish(self, accumulate=False):
+        """Wait for every bucket and hand the averaged gradients back.  ``accumulate=True`` (a micro-step of gradient
+        accumulation: ``update_grad=False`` in the reference's loop, train/pretrain/multimodal.py:260,316-323) keeps
+        the buckets' contents, so the next backward ADDS to the averaged gradients: sum_r (g_prev + g_r) / W =
+        g_prev + mean_r g_r because g_prev is identical on every rank.  Otherwise the sink buckets are re-zeroed
+        before the next step's first contribution."""
         if not self._armed:
             raise RuntimeError('GradReducer.finish() without prepare()')
         self._armed = False
@@ -362,6 +389,13 @@ class GradReducer:
             if not b.launched:        # a hook did not fire (grad was None): flush what we have
                 self._launch(b)
             b.work.wait()
+        self._ready_event = None
+        for sb in self.sinks.values():
+            # acquired in this step but never released to zero (a backward call that was expected did not run):
+            # reduce what it holds now -- every rank walks its sinks in creation order, so ranks that agree on which
+            # passes ran issue the same collectives
+            if sb.work is None and not sb.fresh and not getattr(sb, 'reduced', False):
+                self._launch_sink(sb)
         for sb in self.sinks.values():
             if sb.work is not None:
                 sb.work.wait()
@@ -372,7 +406,7 @@ class GradReducer:
                 if not getattr(sb, 'unpacked', False):
                     self._unpack_sink(sb)
                 sb.work, sb.unpacked = None, False
-            sb.fresh, sb.expected = True, 0
+            sb.fresh, sb.expected, sb.reduced = (not accumulate), 0, False
         for b in self.buckets:
             if b.expected == 0:
                 continue

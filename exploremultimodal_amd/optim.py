@@ -99,7 +99,7 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.adam_w_mode = 1 if adam_w_mode else 0
-        self._tab = None         # (signature, device buffers, host staging, TensorList)
+        self._tabs = {}          # signature -> [device buffers, host staging, TensorList, turn] (a few at most)
         self.last_ctl = None
 
     # ---- tables ------------------------------------------------------------------------------------------
@@ -116,10 +116,13 @@ class FusedAdam(torch.optim.Optimizer):
                 if not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError('FusedAdam: parameters and gradients must be contiguous')
                 st = self.state[p]
-                if len(st) == 0:
-                    st['step'] = torch.tensor(0.)
+                if 'exp_avg' not in st:
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if 'step' not in st:
+                    # apex FusedAdam (the reference's 'fusedadamw') keeps ONE step counter per param group and only
+                    # the moments per parameter: a state dict saved by it resumes from the group's counter
+                    st['step'] = torch.tensor(float(group.get('step', 0)))
                 items.append((gi, p, st))
         return items
 
@@ -127,7 +130,8 @@ class FusedAdam(torch.optim.Optimizer):
         dev = items[0][1].device
         sig = (dev, tuple((id(p), p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()) for _, p, st in items))
         nt = len(items)
-        if self._tab is None or self._tab[0] != sig:
+        tab = self._tabs.get(sig)
+        if tab is None:
             chunk_tensor, chunk_start = [], []
             for t, (_, p, _) in enumerate(items):
                 for off in range(0, p.numel(), CHUNK):
@@ -158,11 +162,12 @@ class FusedAdam(torch.optim.Optimizer):
             # host running steps ahead of the GPU never overwrites a buffer whose upload has not happened yet
             stage = [(torch.empty(nt, dtype=torch.int64).pin_memory(), torch.empty(2 * nt, dtype=torch.float32).pin_memory(),
                       torch.cuda.Event()) for _ in range(4)]
-            self._tab = (sig, (dev_i, dev_f, dev_c, partial, ctl), stage, tl)
-            self._turn = 0
-        _, (dev_i, dev_f, _, partial, ctl), stage, tl = self._tab
-        host_g, host_f, ev = stage[self._turn % len(stage)]
-        self._turn += 1
+            if len(self._tabs) >= 8:        # parameter sets change rarely (frozen / unused parameters): keep a few
+                self._tabs.pop(next(iter(self._tabs)))
+            tab = self._tabs[sig] = [(dev_i, dev_f, dev_c, partial, ctl), stage, tl, 0]
+        (dev_i, dev_f, _, partial, ctl), stage, tl, turn = tab
+        host_g, host_f, ev = stage[turn % len(stage)]
+        tab[3] = turn + 1
         ev.synchronize()
         for t, (gi, p, _) in enumerate(items):
             host_g[t] = p.grad.data_ptr()
@@ -190,24 +195,29 @@ class FusedAdam(torch.optim.Optimizer):
             g = self.param_groups[gi]
             if (g['betas'], g['eps'], g['bias_correction']) != (ref['betas'], ref['eps'], ref['bias_correction']):
                 raise RuntimeError('FusedAdam: betas / eps / bias_correction must be the same in every group')
-        steps = {int(st['step']) for _, _, st in items}
-        if len(steps) != 1:
-            raise RuntimeError('FusedAdam: parameters with different step counts in one step()')
-        step = steps.pop() + 1
+        # per-parameter step counters (torch.optim.AdamW semantics): a parameter that had no gradient in some step
+        # (an objective skipped, find_unused_parameters=True in the reference's DDP wrap) falls behind the others.
+        # The bias corrections are per launch, so parameters are bucketed by step: one launch in the usual case.
+        by_step = {}
+        for it in items:
+            by_step.setdefault(int(it[2]['step']), []).append(it)
         with torch.cuda.device(items[0][1].device):
             tl, partial, ctl = self._tables(items)
             use_ctl = clip_grad is not None or grad_scale != 1.0
-            if use_ctl:
+            if use_ctl:      # the global norm covers every parameter of this step, whatever its counter
                 hip.mt_grad_norm(tl, 1.0 / grad_scale, clip_grad if clip_grad is not None else 0.0, partial, ctl)
             b1, b2 = ref['betas']
-            a = hip.AdamArgs()
-            a.beta1, a.beta2, a.eps = b1, b2, ref['eps']
-            if ref['bias_correction']:
-                a.inv_bc1, a.inv_bc2 = 1.0 / (1.0 - b1 ** step), 1.0 / (1.0 - b2 ** step)
-            else:
-                a.inv_bc1 = a.inv_bc2 = 1.0
-            a.adam_w_mode = self.adam_w_mode
-            hip.mt_adam(tl, a, ctl if use_ctl else None)
+            for step0, its in by_step.items():
+                step = step0 + 1
+                tl_b = tl if len(by_step) == 1 else self._tables(its)[0]
+                a = hip.AdamArgs()
+                a.beta1, a.beta2, a.eps = b1, b2, ref['eps']
+                if ref['bias_correction']:
+                    a.inv_bc1, a.inv_bc2 = 1.0 / (1.0 - b1 ** step), 1.0 / (1.0 - b2 ** step)
+                else:
+                    a.inv_bc1 = a.inv_bc2 = 1.0
+                a.adam_w_mode = self.adam_w_mode
+                hip.mt_adam(tl_b, a, ctl if use_ctl else None)
         # the kernel wrote the parameters and moments behind autograd's back: bump their version counters, which is
         # what invalidates the engine's cached bf16 weight shadows (engine.ShadowCache) and any saved-tensor checks
         touched = [p for _, p, _ in items]
@@ -237,7 +247,7 @@ class NativeScalerWithGradNormCount:
             self.reducer.prepare(loss)
         loss.backward(create_graph=create_graph)
         if self.reducer is not None:
-            self.reducer.finish()
+            self.reducer.finish(accumulate=not update_grad)
         if not update_grad:
             return None
         if isinstance(optimizer, FusedAdam):

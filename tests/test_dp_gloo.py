@@ -129,6 +129,98 @@ def _sink_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _FakeEngineFn(torch.autograd.Function):
+    """Stand-in for engine.StackFn on CPU: registers its sink groups in forward, accumulates `scale` into the sink
+    bucket in backward (what vlmo_stack_bwd does with the weight gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, red, groups, scale):
+        ctx.sink, ctx.sink_groups, ctx.scale = red, [groups], scale
+        for g in groups:
+            red.expect(g)
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, dy):
+        for g in ctx.sink_groups[0]:
+            n = sum(p.numel() for p in g)
+            flat = ctx.sink.acquire(g, n, torch.device('cpu'))
+            flat += ctx.scale
+            for p in g:
+                if p.grad is None:
+                    p.grad = flat[:p.numel()].view_as(p)   # placeholder view, as the engine installs
+        ctx.sink.release_all(ctx.sink_groups[0])
+        return dy, None, None, None
+
+
+def _sink_edge_worker(rank, world, port, q):
+    """(a) a pass whose output is dropped from the loss (train/pretrain/multimodal.py:281-284 drops non-finite task
+    losses): prepare(loss) must count only the engine nodes that will run, else the bucket keeps local gradients;
+    (b) gradient accumulation (update_grad=False micro-steps): finish(accumulate=True) keeps the averaged bucket and
+    the next backward adds to it."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from exploremultimodal_amd.dp import GradReducer
+        model = Tiny()
+        red = GradReducer(model, engine_sink=False)
+        group = tuple(model.blocks[0]['a'].parameters())
+        n = sum(p.numel() for p in group)
+        mean = lambda f: sum(f(r) for r in range(world)) / world
+        for step in range(2):
+            x = torch.ones(3, requires_grad=True)
+            y1 = _FakeEngineFn.apply(x, red, [group], float(rank + 1))
+            y2 = _FakeEngineFn.apply(x, red, [group], 100.0 * (rank + 1))      # this pass is dropped from the loss
+            loss = y1.sum()
+            red.prepare(loss)
+            loss.backward()
+            red.finish()
+            got = red.sinks[red._key(group)].flat[:n]
+            want = mean(lambda r: r + 1.0)
+            assert torch.allclose(got, torch.full_like(got, want)), ('dropped pass', step, got[:3], want)
+            del y2
+        # accumulation: two micro-steps without an optimizer step, then the update step
+        tot = 0.0
+        for micro, acc in enumerate([True, True, False]):
+            x = torch.ones(3, requires_grad=True)
+            y = _FakeEngineFn.apply(x, red, [group], float((rank + 1) * (micro + 1)))
+            loss = y.sum()
+            red.prepare(loss)
+            loss.backward()
+            red.finish(accumulate=acc)
+            tot += mean(lambda r: (r + 1.0) * (micro + 1))
+            got = red.sinks[red._key(group)].flat[:n]
+            assert torch.allclose(got, torch.full_like(got, tot)), ('accumulate', micro, got[:3], tot)
+        # after the update step the bucket starts from zero again
+        x = torch.ones(3, requires_grad=True)
+        loss = _FakeEngineFn.apply(x, red, [group], 1.0).sum()
+        red.prepare(loss)
+        loss.backward()
+        red.finish()
+        got = red.sinks[red._key(group)].flat[:n]
+        assert torch.allclose(got, torch.ones_like(got)), got[:3]
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_sink_dropped_pass_and_accumulation_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_edge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
+
+
 def test_engine_sink_protocol_world2_gloo():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -98,3 +98,16 @@ def test_oracle_matches_torch_adam_on_cpu(adam_w):
     n, c = adamw_oracle.clip_coef(grads, 0.7)
     assert n == pytest.approx(n_ref.item(), rel=1e-6)
     np.testing.assert_allclose(ts[0].grad.numpy(), grads[0] * c, rtol=1e-6)
+
+
+def test_apex_shaped_state_dict_loads_on_cpu():
+    """apex FusedAdam layout (step in the param group, moments per parameter) loads into FusedAdam's state without a
+    device: the counter is taken from the group when the step is next run (optim.FusedAdam._collect)."""
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(3))]
+    opt = optim.FusedAdam(ps, lr=1e-3)
+    sd = opt.state_dict()
+    sd['state'] = {0: {'exp_avg': torch.zeros(4, 3), 'exp_avg_sq': torch.zeros(4, 3)},
+                   1: {'exp_avg': torch.zeros(3), 'exp_avg_sq': torch.zeros(3)}}
+    sd['param_groups'][0]['step'] = 7
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]['step'] == 7 and set(opt.state[ps[0]]) == {'exp_avg', 'exp_avg_sq'}

@@ -165,3 +165,56 @@ def test_train_step_on_the_model_reduces_the_loss():
         assert torch.isfinite(norm).item()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_a_parameter_that_skips_steps_keeps_its_own_counter():
+    """find_unused_parameters semantics (train/pretrain/multimodal.py:83-88): a parameter without a gradient in some
+    steps (an objective skipped) falls behind; every later step must still work and equal torch.optim.AdamW, which
+    keeps per-parameter step counters.  Also with the fused clip (the norm covers every parameter of the step)."""
+    ps = _params(2, [(40, 33), (1000,), (17,)])
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours = optim.FusedAdam(ps, lr=3e-3, betas=(0.9, 0.98), weight_decay=0.02)
+    ref = torch.optim.AdamW(qs, lr=3e-3, betas=(0.9, 0.98), weight_decay=0.02)
+    g = torch.Generator().manual_seed(4)
+    for step in range(6):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            skip = (i == 1 and step in (1, 2)) or (i == 2 and step == 0)     # late starter and a drop-out
+            gr = None if skip else (torch.randn(p.shape, generator=g) * 0.3).to(DEV)
+            p.grad, q.grad = gr, (gr.clone() if gr is not None else None)
+        torch.nn.utils.clip_grad_norm_(qs, 1.5)
+        ref.step()
+        ours.step(clip_grad=1.5)
+    assert [int(ours.state[p]['step']) for p in ps] == [6, 4, 5]
+    for p, q in zip(ps, qs):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-5, atol=5e-7)
+
+
+def test_resume_from_an_apex_shaped_state_dict():
+    """The reference's default optimizer 'fusedadamw' is apex FusedAdam: its state dict keeps `step` in the param
+    group and only exp_avg / exp_avg_sq per parameter.  Loading it must resume from the group's counter."""
+    ps = _params(6, [(30, 10), (10,)])
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours = optim.FusedAdam(ps, lr=1e-2, weight_decay=0.1)
+    ref = torch.optim.AdamW(qs, lr=1e-2, weight_decay=0.1)
+    for k in range(3):
+        for p, q in zip(ps, qs):
+            gr = torch.randn_like(p)
+            p.grad, q.grad = gr, gr.clone()
+        ref.step()
+        if k < 2:
+            ours.step()
+    # rebuild `ours` from an apex-layout dict describing its state after 2 steps
+    sd = copy.deepcopy(ours.state_dict())
+    for st in sd['state'].values():
+        del st['step']
+    for grp in sd['param_groups']:
+        grp['step'] = 2
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    resumed = optim.FusedAdam(rs, lr=1e-2, weight_decay=0.1)
+    resumed.load_state_dict(sd)
+    for r, q in zip(rs, qs):
+        r.grad = q.grad.clone()
+    resumed.step()
+    for r, q in zip(rs, qs):
+        torch.testing.assert_close(r.detach(), q.detach(), rtol=1e-5, atol=2e-7)
+    assert all(int(resumed.state[r]['step']) == 3 for r in rs)
