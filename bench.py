@@ -40,7 +40,7 @@ def fwd_flops_per_pair(d, L, F, T, P=197, patch_k=768):
 
 def build_model(preset, device, drop=0.1):
     from exploremultimodal_amd.vlmo import VLMO, LayerNorm
-    from oracle import synth   # config presets only (shapes); no oracle compute on this path
+    from exploremultimodal_amd import synth
     mc = synth.make_config(preset).model
     torch.manual_seed(0)
     m = VLMO(img_size=mc.img_size, patch_size=mc.patch_size, in_chans=mc.in_chans, num_classes=0,
@@ -53,9 +53,10 @@ def build_model(preset, device, drop=0.1):
     return m.to(device), mc
 
 
-def cpu_baseline(preset, B=8, reps=3):
-    """The CPU oracle (plain PyTorch fp32 restatement of the reference) timed on the host cores:
-    VL forward+backward, same shapes, batch B.  Reported baseline, not a target."""
+def cpu_baseline(preset, B=8, reps=5):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference) timed on the host cores (SURVEY.md 8d):
+    VL forward+backward at batch B (median of `reps` after one warm-up) -> pairs/s, plus BASELINE.json configs[0]
+    (single VL forward, batch 2).  Reported baseline, not a target."""
     from oracle import synth, vlmo_oracle
     # the GPU box exposes many more logical CPUs than this job's share: use the affinity mask, capped at
     # the documented 16-core share of a 1-GPU box (oversubscribing the host stalls for minutes)
@@ -69,22 +70,44 @@ def cpu_baseline(preset, B=8, reps=3):
     sd = synth.synth_backbone_state_dict(mc, 0)
     for t in sd.values():
         t.requires_grad_(True)
-    batch = synth.synth_batch(mc, B, seed=1234, mim=False)
-    im = torch.ones(B, synth.num_img_tokens(mc), dtype=torch.int64)
-    ts = []
-    for r in range(reps + 1):
-        t0 = time.perf_counter()
-        x, _ = vlmo_oracle.forward_features(sd, mc, img=batch['image'], txt=batch['text_ids'], img_attn_masks=im,
-                                            txt_attn_masks=batch['text_mask'])
-        x.square().mean().backward()
-        ts.append(time.perf_counter() - t0)
-        for t in sd.values():
-            t.grad = None
-    ts = sorted(ts[1:])
-    med = ts[len(ts) // 2]
+
+    def run(Bx, backward, n):
+        batch = synth.synth_batch(mc, Bx, seed=1234, mim=False)
+        im = torch.ones(Bx, synth.num_img_tokens(mc), dtype=torch.int64)
+        ts = []
+        for r in range(n + 1):
+            t0 = time.perf_counter()
+            with torch.set_grad_enabled(backward):
+                x, _ = vlmo_oracle.forward_features(sd, mc, img=batch['image'], txt=batch['text_ids'], img_attn_masks=im,
+                                                    txt_attn_masks=batch['text_mask'])
+                if backward:
+                    x.square().mean().backward()
+            ts.append(time.perf_counter() - t0)
+            for t in sd.values():
+                t.grad = None
+        ts = sorted(ts[1:])
+        return ts[len(ts) // 2]
+
+    med = run(B, True, reps)
+    fwd2 = run(2, False, reps)
     return {'value': round(B / med, 3), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle VLMo-Base VL fwd+bwd fp32, batch {B}, median of {reps} after 1 warm-up '
-                      f'({med:.2f} s per step)'}
+            'sample': f'oracle VLMo-{preset} VL fwd+bwd fp32, batch {B}, median of {reps} after 1 warm-up '
+                      f'({med:.2f} s per step); configs[0] single VL forward at batch 2: {fwd2:.3f} s '
+                      f'({2 / fwd2:.2f} pairs/s forward only)',
+            'config0_forward_b2_s': round(fwd2, 4)}
+
+
+def _latest_profile(suffix):
+    """Newest profiles/rNN*<suffix> by round number (the PMC passes of this same command are committed per round)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*' + suffix)):
+        m = re.match(r'r(\d\d)(.*)', os.path.basename(f))
+        key = (int(m.group(1)), m.group(2))
+        if best is None or key > best[0]:
+            best = (key, f)
+    return best[1] if best else None
 
 
 def main():
@@ -140,7 +163,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
 
     from exploremultimodal_amd import engine, hip
-    from oracle import synth
+    from exploremultimodal_amd import synth
     hip.lib()
     drop = 0.0 if args.no_dropout else 0.1
     if args.objective == 'full':
@@ -227,8 +250,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item(), 'non-finite loss'
-
-    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue {t_issue / args.steps * 1e3:.2f} ms/step)')
+    # host cost of enqueueing one step, measured with an EMPTY device queue (in the timed loop above the host runs
+    # ahead until the launch queue is full and then waits for the GPU: t_issue there is back-pressure, not host work)
+    hs = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        hs.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    host_ms = sorted(hs)[1] * 1e3
+    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue with an empty queue {host_ms:.2f} ms/step; '
+        f'{t_issue / args.steps * 1e3:.2f} ms/step while the queue is full)')
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = B * world * args.steps / dt
@@ -251,20 +284,27 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
                     'launches_per_step': n // args.steps, 'avg_launch_us': round(tsec / n * 1e6, 2),
                     'flops_per_launch': round(flops / n)}
+        pmc = None
         if roof is not None:        # HBM bytes per launch from the committed PMC passes of this same command
             try:
                 import re
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_f_traffic.json')))['kernels']
-                m = re.match(r'(gemm_[nt]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', roof['kernel'])
+                tf = _latest_profile('traffic.json')
+                pmc = json.load(open(tf))
+                tr = pmc['kernels']
+                m = re.match(r'(gemm_[a-z_]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', roof['kernel'])
                 epi = {'bias': 0, 'bias_gelu': 1, 'resid': 2, 'dgelu': 3, 'f32': 4, 'dual': 5, 'argmax': 6}
-                pat = f'{m.group(1)}IDF16bLi{m.group(3)}ELi{m.group(4)}ELi\\dELi\\dE'
-                if m.group(2):
-                    pat += f'Li{epi[m.group(2)]}E'
+                if 'multi' in m.group(1):
+                    pat = m.group(1)
+                else:
+                    pat = f'{m.group(1)}IDF16bLi{m.group(3)}ELi{m.group(4)}ELi\\dELi\\dE'
+                    if m.group(2):
+                        pat += f'Li{epi[m.group(2)]}E'
                 for k, v in tr.items():
                     if re.search(pat, k):
                         roof['traffic'] = round(v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
+                        roof['traffic_source'] = os.path.relpath(tf, ROOT)
                         break
-            except (OSError, KeyError, ValueError, AttributeError):
+            except (OSError, KeyError, ValueError, AttributeError, TypeError):
                 pass
         out = {
             'metric': 'image-text pairs/sec fwd+bwd, VLMo-Base, 1/2/4/8 MI355X; % bf16 MFMA roofline',
@@ -287,6 +327,14 @@ def main():
             'kernels': {k: {'s_per_step': round(v[0] / args.steps, 6), 'tflops': round(v[1] / v[0] / 1e12, 1)}
                         for k, v in per.items()},
         }
+        # north_star: "rocprof HBM GB/s and MFMA-busy counters reported against chip peak" -- whole-step figures from
+        # the committed PMC passes of this same command (profiles/rNN_*traffic.json, tools/summarize_pmc.py)
+        if pmc is not None and 'step' in pmc:
+            out['hbm_gbs'] = pmc['step'].get('hbm_gbs')
+            out['hbm_frac'] = round(pmc['step'].get('hbm_gbs', 0) / PEAK_HBM_GBS, 4) if pmc['step'].get('hbm_gbs') else None
+            out['mfma_busy'] = pmc['step'].get('mfma_busy')
+            out['pmc_source'] = os.path.relpath(_latest_profile('traffic.json'), ROOT)
+        out['host_enqueue_ms'] = round(host_ms, 3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.preset)
         sys.stdout.flush()

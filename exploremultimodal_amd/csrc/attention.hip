@@ -55,11 +55,22 @@ __device__ __forceinline__ void stage_image(const bf16* base, int ld, int col0, 
     }
 }
 
-__device__ __forceinline__ uint64_t att_drop_group(int bh, int q, int key) {
-    return ((uint64_t)bh * 4096 + q) * 1024 + (key >> 2);
+// ---- attention dropout (vlmo.py:93): counter-based, regenerated in the backward -------------------------------
+// keep(seq*heads + head, q, key) <=> u16 >= thresh with u16 = half (key & 1) of att_mix(c * G + att_key),
+// c = q * 512 + (key >> 1).  One multiply round (the probabilities are ~26 VALU instructions per score element in
+// these kernels and VALU issue is what bounds them: the two-round hash32 + 64-bit counter cost 17 of them in the
+// dK/dV phase); a lane owning a query gets two keys per hash, a lane owning a key one element per hash, and the
+// counter is affine in both q and key so either orientation advances it with ONE add of a compile-time constant.
+#define ATT_G 0x9E3779B1u
+#define ATT_G512 ((uint32_t)(512ull * ATT_G))
+__device__ __forceinline__ uint32_t att_key(uint64_t seed, int bh) {
+    return hash32((uint32_t)seed ^ ((uint32_t)bh * 0x9E3779B9u)) + (uint32_t)(seed >> 32);
 }
-__device__ __forceinline__ uint64_t att_drop_bits(uint64_t seed, int bh, int q, int key) {
-    return drop_bits4(seed, att_drop_group(bh, q, key));
+__device__ __forceinline__ uint32_t att_mix(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    return x;
 }
 
 // B/A operand by row read: rows row_base + (lane&31), features 16*ks + 8*(lane>>5) ..+7
@@ -121,9 +132,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
     __syncthreads();
 
     const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t akey = att_key(a.seed, bh);
     for (int qt = wave; qt < nq; qt += 4) {
         const int qi = qt * 32 + l31;
         const int qrow = rowidx[qi];
+        const uint32_t rq = ((uint32_t)qi * 512u + 2u * h) * ATT_G + akey;     // dropout counter base of this lane
         const bf16* qp = a.qkv + (size_t)qrow * ld + hd * 64 + 8 * h;
         bf16x8 qf[4];
 #pragma unroll
@@ -181,13 +194,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
                 const int kt = c0 + c;
                 if (kt < nq) {
                     if (a.drop_thresh) {
+                        const uint32_t rk = rq + (uint32_t)(kt * 16) * ATT_G;
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const uint64_t bits = att_drop_bits(a.seed, bh, qi, kt * 32 + 8 * g4 + 4 * h);
+                        for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (!drop_keep(bits, e, a.drop_thresh)) S[c][4 * g4 + e] = 0.f;
-                        }
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const uint32_t r = att_mix(rk + (uint32_t)(4 * g4 + jj) * ATT_G);
+                                if ((r & 0xFFFFu) < a.drop_thresh) S[c][4 * g4 + 2 * jj] = 0.f;
+                                if ((r >> 16) < a.drop_thresh) S[c][4 * g4 + 2 * jj + 1] = 0.f;
+                            }
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
@@ -251,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     stage_image<8>(a.qkv, ld, a.d + hd * 64, rowidx, Kimg, nq * 4, wave, lane);
     stage_image<8>(a.qkv, ld, 2 * a.d + hd * 64, rowidx, Vimg, nq * 4, wave, lane);
     stage_image<8>(a.dctx, a.d, hd * 64, rowidx, Dimg, nq * 4, wave, lane);
+    const float keep_prob = 1.f / a.inv_keep;
     for (int i = threadIdx.x; i < NPAD; i += 512) {
         float dl = 0.f, lq = INFINITY;
         if (i < N) {
@@ -264,13 +280,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             }
             lq = a.lse[(size_t)bh * a.lse_stride + i] * LOG2E;
         }
-        delta[i] = dl;
+        delta[i] = dl * keep_prob;      // dS = scale * inv_keep * P * (keep * dP - delta / inv_keep): see below
         lseq[i] = lq;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int l31 = lane & 31, h = lane >> 5;
+    const uint32_t akey = att_key(a.seed, bh);
+    // the constant factors of dS = P * (keep * dP * inv_keep - delta) * scale and Pd = keep * P * inv_keep are
+    // applied ONCE to the 32 accumulator values a lane owns, not to every score element
+    const float out_scale = a.scale * a.inv_keep;
 
     for (;;) {
     int item = 0;
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             df[s] = row_frag(Dimg, qt * 32, s, lane);
         }
         const float lq = lseq[qi], dl = delta[qi];
+        const uint32_t rq = ((uint32_t)qi * 512u + 2u * h) * ATT_G + akey;
         f32x16 dQ[2] = {zero16(), zero16()};
         for (int kt = 0; kt < nq; ++kt) {
             {
@@ -297,18 +318,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                     S = Elem<bf16>::mfma(row_frag(Kimg, kt * 32, s, lane), qf[s], S);
                     dP = Elem<bf16>::mfma(row_frag(Vimg, kt * 32, s, lane), df[s], dP);
                 }
+                const uint32_t rk = rq + (uint32_t)(kt * 16) * ATT_G;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 kb = *(const f32x4*)(kbias + kt * 32 + 8 * g4 + 4 * h);
-                    uint64_t bits = 0;
-                    if (a.drop_thresh) bits = att_drop_bits(a.seed, bh, qi, kt * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * g4 + e;
-                        const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + kb[e] - lq);
-                        float dp = dP[i];
-                        if (a.drop_thresh) dp = drop_keep(bits, e, a.drop_thresh) ? dp * a.inv_keep : 0.f;
-                        S[i] = p * (dp - dl) * a.scale;
+                    for (int jj = 0; jj < 2; ++jj) {
+                        uint32_t r = 0xFFFFFFFFu;
+                        if (a.drop_thresh) r = att_mix(rk + (uint32_t)(4 * g4 + jj) * ATT_G);
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int e = 2 * jj + e2, i = 4 * g4 + e;
+                            const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + (kb[e] - lq));
+                            const bool keep = (e2 ? (r >> 16) : (r & 0xFFFFu)) >= a.drop_thresh;
+                            const float dp = keep ? dP[i] : 0.f;
+                            S[i] = p * (dp - dl);
+                        }
                     }
                 }
 #pragma unroll
@@ -328,8 +353,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    bf16x4 o = {(bf16)dQ[dt][4 * g4 + 0], (bf16)dQ[dt][4 * g4 + 1], (bf16)dQ[dt][4 * g4 + 2],
-                                (bf16)dQ[dt][4 * g4 + 3]};
+                    bf16x4 o = {(bf16)(dQ[dt][4 * g4 + 0] * out_scale), (bf16)(dQ[dt][4 * g4 + 1] * out_scale),
+                                (bf16)(dQ[dt][4 * g4 + 2] * out_scale), (bf16)(dQ[dt][4 * g4 + 3] * out_scale)};
                     *(bf16x4*)(op + dt * 32 + 8 * g4) = o;
                 }
         }
@@ -346,6 +371,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             vf[s] = row_frag(Vimg, kt * 32, s, lane);
         }
         const float kb = kbias[ki];
+        // dropout counter of (q, ki) = q * 512 + (ki >> 1): affine in q, so a lane walks its 16 queries of a tile
+        // with compile-time constant adds; its element is the (ki & 1) half of the hash
+        const uint32_t rl = (uint32_t)(ki >> 1) * ATT_G + akey + (uint32_t)(4 * h) * ATT_G512;
+        const uint32_t rsh = 16u * (ki & 1);
         f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};
         for (int qt = 0; qt < nq; ++qt) {
             {
@@ -356,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                     dP = Elem<bf16>::mfma(row_frag(Dimg, qt * 32, s, lane), vf[s], dP);
                 }
                 f32x16 Pd;
+                const uint32_t rqt = rl + (uint32_t)(qt * 32) * ATT_G512;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int q0 = qt * 32 + 8 * g4 + 4 * h;
@@ -364,15 +394,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g4 + e;
-                        const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + kb - lq[e]);
-                        float dp = dP[i], pd = p;
-                        if (a.drop_thresh) {
-                            const bool keep = drop_keep1(a.seed, att_drop_group(bh, q0 + e, ki), ki & 3, a.drop_thresh);
-                            dp = keep ? dp * a.inv_keep : 0.f;
-                            pd = keep ? p * a.inv_keep : 0.f;
-                        }
-                        Pd[i] = pd;
-                        S[i] = p * (dp - dl[e]) * a.scale;
+                        const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + (kb - lq[e]));
+                        bool keep = true;
+                        if (a.drop_thresh)
+                            keep = __builtin_amdgcn_ubfe(att_mix(rqt + (uint32_t)(8 * g4 + e) * ATT_G512), rsh, 16u) >= a.drop_thresh;
+                        Pd[i] = keep ? p : 0.f;
+                        S[i] = p * ((keep ? dP[i] : 0.f) - dl[e]);
                     }
                 }
 #pragma unroll
@@ -397,10 +424,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    bf16x4 ok = {(bf16)dK[dt][4 * g4 + 0], (bf16)dK[dt][4 * g4 + 1], (bf16)dK[dt][4 * g4 + 2],
-                                 (bf16)dK[dt][4 * g4 + 3]};
-                    bf16x4 ov = {(bf16)dV[dt][4 * g4 + 0], (bf16)dV[dt][4 * g4 + 1], (bf16)dV[dt][4 * g4 + 2],
-                                 (bf16)dV[dt][4 * g4 + 3]};
+                    bf16x4 ok = {(bf16)(dK[dt][4 * g4 + 0] * out_scale), (bf16)(dK[dt][4 * g4 + 1] * out_scale),
+                                 (bf16)(dK[dt][4 * g4 + 2] * out_scale), (bf16)(dK[dt][4 * g4 + 3] * out_scale)};
+                    bf16x4 ov = {(bf16)(dV[dt][4 * g4 + 0] * a.inv_keep), (bf16)(dV[dt][4 * g4 + 1] * a.inv_keep),
+                                 (bf16)(dV[dt][4 * g4 + 2] * a.inv_keep), (bf16)(dV[dt][4 * g4 + 3] * a.inv_keep)};
                     *(bf16x4*)(op + a.d + dt * 32 + 8 * g4) = ok;
                     *(bf16x4*)(op + 2 * a.d + dt * 32 + 8 * g4) = ov;
                 }

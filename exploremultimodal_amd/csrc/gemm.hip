@@ -667,6 +667,31 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
     // epilogue: lane = output column, register = output row: each half-wave
     // writes / adds 128 contiguous bytes
     const int l31 = lane & 31;
+    if (!p.slab && p.mode == TN_ACCUM) {
+        // in-place accumulate by the tile's only owner: all 16 loads of a 32x32 sub-tile are issued before the
+        // first add (one HBM round trip per sub-tile; a load -> add -> store chain per element costs 128 of them,
+        // ~200 us per workgroup in the first build of this kernel)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n2_0 + wn * (BN / WN) + j * 32 + l31;
+                const int gm0 = n1_0 + wm * (BM / WM) + i * 32 + 4 * h;
+                const bool okn = gn < p.N2;
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = gm0 + (r & 3) + 8 * (r >> 2);
+                    old[r] = (okn && gm < p.N1) ? p.C[(size_t)gm * p.ldc + gn] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = gm0 + (r & 3) + 8 * (r >> 2);
+                    if (okn && gm < p.N1) p.C[(size_t)gm * p.ldc + gn] = old[r] + p.alpha * acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -681,8 +706,6 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
                         p.slab[((size_t)split * p.N1 + gm) * p.N2 + gn] = acc[i][j][r];
                     else if (p.mode == TN_STORE)
                         *c = p.alpha * acc[i][j][r];
-                    else if (p.mode == TN_ACCUM)
-                        *c += p.alpha * acc[i][j][r];
                     else
                         atomicAdd(c, p.alpha * acc[i][j][r]);
                 }

@@ -1,246 +1,5 @@
-"""Deterministic synthetic configs, weights and batches (test infrastructure).
-
-The reference ships no checkpoints and random init depends on module
-construction order, so golden vectors are produced from weights generated by a
-*key-addressed* recipe: every state-dict entry is drawn from its own
-``torch.Generator`` seeded by a hash of (seed, key).  The same recipe runs in
-the build container (to load the reference model and record its outputs) and
-on the GPU box (to rebuild identical weights for the HIP path and the oracle).
-
-Config fields follow the reference YAMLs (conf/model/vlmo_base.yaml:1-28,
-conf/model/vlmo_large.yaml:1-28, conf/model/vlmo_debug.yaml:1-28) and the
-train-section fields read by VlmoModule (models/vlmo/vlmo_module.py:16-167).
-Batch keys follow data/datasets/base_dataset.py:88-168.
-"""
-import hashlib
-import math
-from types import SimpleNamespace
-
-import torch
-
-_MODEL_DEFAULTS = dict(
-    type='VLMO', itc_temp=0.07, itc_dim=256, img_vocab_size=8192,
-    vocab_size=30522, max_text_len=64, img_size=224, patch_size=16,
-    in_chans=3, num_classes=0, mlp_ratio=4, qkv_bias=True, drop_rate=0.0,
-    attn_drop_rate=0.0, drop_path_rate=0.0, norm_layer='fused_norm')
-
-_PRESETS = {
-    # BASELINE.json fixes T=64 (legal value of max_text_len, vlmo.py:220,254)
-    'base': dict(name='vlmo_base', embed_dim=768, depth=12, num_heads=12,
-                 init_values=0.1, fusion_layer=6),
-    'large': dict(name='vlmo_large', embed_dim=1024, depth=24, num_heads=16,
-                  init_values=1e-5, fusion_layer=12),
-    # the reference's own debug shape (head_dim 32; oracle-only)
-    'debug': dict(name='vlmo_debug', embed_dim=96, depth=2, num_heads=3,
-                  init_values=0.1, fusion_layer=1, itc_dim=32,
-                  max_text_len=40),
-    # small shape with the production head_dim (64) for HIP parity tests
-    'mini': dict(name='vlmo_mini', embed_dim=128, depth=2, num_heads=2,
-                 init_values=0.1, fusion_layer=1, itc_dim=32, img_size=64,
-                 max_text_len=16, vocab_size=1024, img_vocab_size=512),
-    # mid-size: ragged sequence tiles (N=50+24), 3 layers
-    'small': dict(name='vlmo_small', embed_dim=256, depth=3, num_heads=4,
-                  init_values=0.1, fusion_layer=2, itc_dim=64, img_size=112,
-                  max_text_len=24, vocab_size=2048, img_vocab_size=512),
-}
-
-
-def make_config(preset='base', loss_names=(), phase='pretrain_mum', **over):
-    m = dict(_MODEL_DEFAULTS)
-    m.update(_PRESETS[preset])
-    m.update(over)
-    train = SimpleNamespace(
-        phase=phase, loss_names=list(loss_names), fixed_attn=False,
-        discrete_vae_weight_path=None, discrete_vae_type='dall-e',
-        global_reduce=False, neg_queue=False, queue_size=0,
-        mim_head_pos='img', isda_lambda=0.0)
-    return SimpleNamespace(model=SimpleNamespace(**m), train=train,
-                           vlmo_ema=False, vlmo_ema_decay=0.999)
-
-
-def num_img_tokens(mc):
-    return (mc.img_size // mc.patch_size) ** 2 + 1
-
-
-def _gen(seed, key):
-    h = hashlib.sha256(f'{seed}:{key}'.encode()).digest()
-    g = torch.Generator()
-    g.manual_seed(int.from_bytes(h[:7], 'little'))
-    return g
-
-
-def _normal(seed, key, shape, std=1.0, mean=0.0):
-    return torch.randn(shape, generator=_gen(seed, key)) * std + mean
-
-
-def backbone_shapes(mc, experts_per_layer=None):
-    """(key -> shape) of the VLMO state dict (SURVEY.md section 8b key list).
-
-    experts_per_layer[i] lists the experts present in block i; by default the
-    pretrain_mum layout of _freeze_params (vlmo_module.py:165-167): no 'vl'
-    expert below the fusion layer.
-    """
-    d, L, F = mc.embed_dim, mc.depth, mc.fusion_layer
-    hid = int(d * mc.mlp_ratio)
-    P = num_img_tokens(mc)
-    s = {
-        'pos_embed': (1, P, d), 'img_cls_token': (1, 1, d),
-        'img_mask_token': (1, 1, d),
-        'patch_embed.proj.weight': (d, mc.in_chans, mc.patch_size,
-                                    mc.patch_size),
-        'patch_embed.proj.bias': (d,),
-        'txt_embeddings.word_embeddings.weight': (mc.vocab_size, d),
-        'txt_embeddings.position_embeddings.weight': (mc.max_text_len, d),
-        'txt_embeddings.token_type_embeddings.weight': (2, d),
-        'txt_embeddings.LayerNorm.weight': (d,),
-        'txt_embeddings.LayerNorm.bias': (d,),
-        'token_type_embeddings.weight': (2, d),
-        'norm.weight': (d,), 'norm.bias': (d,),
-        'pooler.dense.weight': (d, d), 'pooler.dense.bias': (d,),
-    }
-    for i in range(L):
-        p = f'blocks.{i}.'
-        s[p + 'gamma_1'] = (d,)
-        s[p + 'gamma_2'] = (d,)
-        for n in ('norm1', 'norm2'):
-            s[p + n + '.weight'] = (d,)
-            s[p + n + '.bias'] = (d,)
-        s[p + 'attn.q_bias'] = (d,)
-        s[p + 'attn.v_bias'] = (d,)
-        s[p + 'attn.qkv.weight'] = (3 * d, d)
-        s[p + 'attn.proj.weight'] = (d, d)
-        s[p + 'attn.proj.bias'] = (d,)
-        if experts_per_layer is not None:
-            experts = experts_per_layer[i]
-        else:
-            experts = ('v', 'l') if i < F else ('v', 'l', 'vl')
-        for e in experts:
-            s[p + f'mlp.{e}.fc1.weight'] = (hid, d)
-            s[p + f'mlp.{e}.fc1.bias'] = (hid,)
-            s[p + f'mlp.{e}.fc2.weight'] = (d, hid)
-            s[p + f'mlp.{e}.fc2.bias'] = (d,)
-    return s
-
-
-def synth_backbone_state_dict(mc, seed=0, experts_per_layer=None):
-    """fp32 state dict with 'trained-like' magnitudes (not the init recipe).
-
-    Matrices ~ N(0, 0.02); biases ~ N(0, 0.02); LayerNorm weight 1+N(0,0.1),
-    bias N(0,0.05); layer-scale gamma 0.5+N(0,0.1) so that every block moves
-    the residual stream visibly (a wrong kernel must show up in the output).
-    """
-    sd = {}
-    for k, shp in backbone_shapes(mc, experts_per_layer).items():
-        leaf = k.split('.')[-1]
-        if 'gamma_' in k:
-            t = _normal(seed, k, shp, 0.1, 0.5)
-        elif ('norm' in k or 'LayerNorm' in k) and leaf == 'weight':
-            t = _normal(seed, k, shp, 0.1, 1.0)
-        elif ('norm' in k or 'LayerNorm' in k) and leaf == 'bias':
-            t = _normal(seed, k, shp, 0.05)
-        elif k == 'patch_embed.proj.weight':
-            fan_in = shp[1] * shp[2] * shp[3]
-            t = _normal(seed, k, shp, 1.0 / math.sqrt(fan_in))
-        else:
-            t = _normal(seed, k, shp, 0.02)
-        sd[k] = t.contiguous()
-    return sd
-
-
-def synth_batch(mc, B, seed=1234, pad=True, mim=True):
-    """Synthetic batch dict per SURVEY.md section 8d ('Synthetic inputs')."""
-    g = torch.Generator()
-    g.manual_seed(seed)
-    T = mc.max_text_len
-    grid = mc.img_size // mc.patch_size
-    image = torch.randn(B, mc.in_chans, mc.img_size, mc.img_size, generator=g)
-    lo = min(1000, mc.vocab_size // 2)
-    ids = torch.randint(lo, mc.vocab_size, (B, T), generator=g)
-    ids[:, 0] = 101 % mc.vocab_size
-    mask = torch.ones(B, T, dtype=torch.int64)
-    if pad:
-        for b in range(B):
-            if b % 2 == 1:
-                p0 = int(torch.randint(max(2, T // 4), T, (1,), generator=g))
-                mask[b, p0:] = 0
-                ids[b, p0:] = 0
-    batch = {'image': image, 'text_ids': ids, 'text_mask': mask}
-    if mim:
-        n_mask = min(75, (grid * grid * 3) // 8)
-        bm = torch.zeros(B, grid * grid, dtype=torch.int64)
-        for b in range(B):
-            perm = torch.randperm(grid * grid, generator=g)[:n_mask]
-            bm[b, perm] = 1
-        batch['image_bool_masked_pos'] = bm.view(B, grid, grid)
-        batch['image4dalle'] = 0.8 * torch.rand(
-            B, 3, mc.img_size // 2, mc.img_size // 2, generator=g) + 0.1
-    # MLM: 15% of non-pad, non-CLS positions -> [MASK]=103 (config.yaml:37)
-    ids_mlm = ids.clone()
-    labels = torch.full_like(ids, -100)
-    sel = (torch.rand(B, T, generator=g) < 0.15) & (mask == 1)
-    sel[:, 0] = False
-    labels[sel] = ids[sel]
-    ids_mlm[sel] = 103 % mc.vocab_size
-    batch['text_ids_mlm'] = ids_mlm
-    batch['text_labels_mlm'] = labels
-    batch['text_labels'] = torch.full_like(ids, -100)
-    return batch
-
-
-# ----------------------------------------------------------------- dVAE ---
-
-def dvae_conv_specs(n_hid=256, vocab_size=8192, input_channels=3,
-                    group_count=4, n_blk_per_group=2):
-    """[(key_prefix, n_in, n_out, kw)] in module order (dall_e/encoder.py:74-121)."""
-    specs = [('blocks.input', input_channels, n_hid, 7)]
-    widths = [1, 2, 4, 8]
-    prev = n_hid
-    for gi in range(group_count):
-        n_out = widths[gi] * n_hid
-        for bi in range(n_blk_per_group):
-            n_in = prev if bi == 0 else n_out
-            p = f'blocks.group_{gi + 1}.block_{bi + 1}'
-            if n_in != n_out:
-                specs.append((p + '.id_path', n_in, n_out, 1))
-            hid = n_out // 4
-            specs.append((p + '.res_path.conv_1', n_in, hid, 3))
-            specs.append((p + '.res_path.conv_2', hid, hid, 3))
-            specs.append((p + '.res_path.conv_3', hid, hid, 3))
-            specs.append((p + '.res_path.conv_4', hid, n_out, 1))
-        prev = n_out
-    specs.append(('blocks.output.conv', prev, vocab_size, 1))
-    return specs
-
-
-def synth_dvae_state_dict(seed=0, **kw):
-    """Key-addressed version of the dall_e init recipe (dall_e/utils.py:24-34:
-    w ~ N(0, 1/sqrt(n_in*kw^2)), b = 0) with small non-zero biases so the bias
-    path is exercised."""
-    sd = {}
-    for p, n_in, n_out, k in dvae_conv_specs(**kw):
-        sd[p + '.w'] = _normal(seed, p + '.w', (n_out, n_in, k, k),
-                               1.0 / math.sqrt(n_in * k * k))
-        sd[p + '.b'] = _normal(seed, p + '.b', (n_out,), 0.02)
-    return sd
-
-
-def synth_head_state_dict(mc, seed=0, loss_names=('mlm', 'mim', 'itc', 'itm')):
-    """Heads of VlmoModule (models/vlmo/heads.py:86-138); keys as in the module's state dict.
-    mlm_head.decoder.weight is tied to the word embedding and therefore not listed."""
-    d, sd = mc.embed_dim, {}
-    lin = lambda k, o, i: sd.update({k + '.weight': _normal(seed, k + '.weight', (o, i), 0.05),
-                                     k + '.bias': _normal(seed, k + '.bias', (o,), 0.02)})
-    if 'mlm' in loss_names:
-        lin('mlm_head.transform.dense', d, d)
-        sd['mlm_head.transform.LayerNorm.weight'] = _normal(seed, 'mlm.ln.w', (d,), 0.1, 1.0)
-        sd['mlm_head.transform.LayerNorm.bias'] = _normal(seed, 'mlm.ln.b', (d,), 0.05)
-        sd['mlm_head.bias'] = _normal(seed, 'mlm_head.bias', (mc.vocab_size,), 0.02)
-    if 'itc' in loss_names:
-        lin('itc_head.dense.v', mc.itc_dim, d)
-        lin('itc_head.dense.l', mc.itc_dim, d)
-        sd['itc_temp'] = torch.tensor(math.log(1 / mc.itc_temp))
-    if 'itm' in loss_names:
-        lin('itm_head.fc', 2, d)
-    if 'mim' in loss_names:
-        lin('mim_head.fc', mc.img_vocab_size, d)
-    return sd
+"""Re-export of exploremultimodal_amd.synth (synthetic configs / weights / batches) for the oracle-side scripts and
+tests.  The generator itself is input generation, not reference arithmetic, and lives in the package so that the
+product benchmark never imports anything under oracle/ except for its cpu_baseline leg."""
+from exploremultimodal_amd.synth import *  # noqa: F401,F403
+from exploremultimodal_amd.synth import _gen, _normal  # noqa: F401

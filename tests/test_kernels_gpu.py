@@ -227,18 +227,18 @@ def _hash32(x):
 
 def _attn_keep_mask(seed, nseq, heads, N, thresh):
     """[nseq, heads, N(q), N(key)] bool: the keep mask of the attention kernels' counter-based dropout
-    (csrc/common.h drop_half / drop_keep, csrc/attention.hip att_drop_group)."""
+    (csrc/attention.hip att_key / att_mix): u16 = half (key & 1) of mix((q * 512 + (key >> 1)) * G + key(seed, bh))."""
     m = np.uint64(0xFFFFFFFF)
     bh = (np.arange(nseq, dtype=np.uint64)[:, None] * np.uint64(heads) + np.arange(heads, dtype=np.uint64)[None, :])
-    q = np.arange(N, dtype=np.uint64)
-    key = np.arange(N, dtype=np.uint64)
-    group = ((bh[:, :, None, None] * np.uint64(4096) + q[None, None, :, None]) * np.uint64(1024)
-             + (key[None, None, None, :] >> np.uint64(2)))
-    j = key[None, None, None, :] & np.uint64(3)
-    i = (group * np.uint64(2) + (j >> np.uint64(1))) & m
     lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
-    h = _hash32((((i ^ lo) & m) * np.uint64(0x9E3779B9) + hi) & m)
-    field = (h >> (np.uint64(16) * (j & np.uint64(1)))) & np.uint64(0xFFFF)
+    akey = (_hash32((lo ^ ((bh * np.uint64(0x9E3779B9)) & m)) & m) + hi) & m
+    q = np.arange(N, dtype=np.uint64)[None, None, :, None]
+    key = np.arange(N, dtype=np.uint64)[None, None, None, :]
+    x = ((((q * np.uint64(512) + (key >> np.uint64(1))) & m) * np.uint64(0x9E3779B1)) + akey[:, :, None, None]) & m
+    x = x ^ (x >> np.uint64(16))
+    x = (x * np.uint64(0x7feb352d)) & m
+    x = x ^ (x >> np.uint64(15))
+    field = (x >> (np.uint64(16) * (key & np.uint64(1)))) & np.uint64(0xFFFF)
     return torch.from_numpy(field >= np.uint64(thresh))
 
 

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from exploremultimodal_amd import engine, hip
-from oracle import synth
+from exploremultimodal_amd import synth
 dev = torch.device('cuda', 0)
 model, mc = bench.build_model('base', dev)
 model.train()
