@@ -208,7 +208,7 @@ class GradReducer:
             self._pending_expect = getattr(self, '_pending_expect', {})
             self._pending_expect[key] = self._pending_expect.get(key, 0) + 1
 
-    def acquire(self, group, numel, device, arena_key=None, arena_numel=0):
+    def acquire(self, group, numel, device, arena_key=None, arena_numel=0, layout=None):
         """Flat fp32 storage for one parameter group of a block call.  ``arena_key`` (any hashable naming the block)
         places the groups of one block next to each other (``arena_numel`` = room for all of them) so that
         release_all() can reduce them in one collective."""
@@ -222,6 +222,8 @@ class GradReducer:
                     pad = self.world * 8
                     arena = self.arenas[arena_key] = _Arena(arena_numel + 4 * pad, device, self.comm_dtype)
             sb = _SinkBucket(numel, device, self.comm_dtype, self.world, arena)
+            sb.params = tuple(group)
+            sb.layout = layout          # [(parameter, offset in the flat bucket)]: what zero.ZeroAdam shards
             sb.expected = getattr(self, '_pending_expect', {}).pop(key, 1)
             self.sinks[key] = sb
             self._sink_params.update(key)
@@ -307,8 +309,13 @@ class GradReducer:
             else:
                 sb.flat.mul_(1.0 / self.world)
             if self.reduce_scatter:
-                sb.shard = torch.empty(sb.padded // self.world, dtype=sb.comm.dtype, device=self.device)
-                sb.work = dist.reduce_scatter_tensor(sb.shard, sb.comm, group=self.pg, async_op=True)
+                # persistent buffers: the ZeRO-2 optimizer (zero.ZeroAdam) keeps device tables of their addresses
+                n = sb.padded // self.world
+                if getattr(sb, 'shard_comm', None) is None:
+                    sb.shard_comm = torch.empty(n, dtype=sb.comm.dtype, device=self.device)
+                    sb.shard32 = sb.shard_comm if sb.comm.dtype == torch.float32 else torch.empty(
+                        n, dtype=torch.float32, device=self.device)
+                sb.work = dist.reduce_scatter_tensor(sb.shard_comm, sb.comm, group=self.pg, async_op=True)
             else:
                 sb.work = dist.all_reduce(sb.comm, group=self.pg, async_op=True)
             if self.on_gpu:
@@ -320,7 +327,9 @@ class GradReducer:
 
     def _unpack_sink(self, sb):
         if self.reduce_scatter:
-            sb.shard = sb.shard.float()
+            if sb.shard32 is not sb.shard_comm:
+                sb.shard32.copy_(sb.shard_comm)
+            sb.shard = sb.shard32
         elif sb.comm is not sb.flat:
             sb.flat.copy_(sb.comm)               # ONE pass: bf16 -> fp32 unpack (already averaged)
         sb.unpacked = True
@@ -357,8 +366,11 @@ class GradReducer:
                 b.had.append(has)
             if self.reduce_scatter:
                 n = b.padded // self.world
-                b.shard = torch.empty(n, dtype=b.comm.dtype, device=self.device)
-                b.work = dist.reduce_scatter_tensor(b.shard, b.comm, group=self.pg, async_op=True)
+                if getattr(b, 'shard_comm', None) is None:
+                    b.shard_comm = torch.empty(n, dtype=b.comm.dtype, device=self.device)
+                    b.shard32 = b.shard_comm if b.comm.dtype == torch.float32 else torch.empty(
+                        n, dtype=torch.float32, device=self.device)
+                b.work = dist.reduce_scatter_tensor(b.shard_comm, b.comm, group=self.pg, async_op=True)
             else:
                 b.work = dist.all_reduce(b.comm, group=self.pg, async_op=True)
             if self.on_gpu:
@@ -368,7 +380,9 @@ class GradReducer:
 
     def _unpack(self, b):
         if self.reduce_scatter:
-            b.shard = b.shard.float()
+            if b.shard32 is not b.shard_comm:
+                b.shard32.copy_(b.shard_comm)
+            b.shard = b.shard32
         elif b.comm is not b.flat:
             b.flat.copy_(b.comm)                     # bf16 -> fp32 unpack (already averaged)
         b.unpacked = True

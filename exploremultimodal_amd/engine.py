@@ -261,6 +261,26 @@ def _carve(flat, shapes):
     return out
 
 
+def shared_layout(params, d):
+    """[(parameter, offset)] of a block's shared-parameter group inside its flat gradient bucket (the carve order of
+    _fill_grads; params in BlockFn's order).  q_bias / v_bias sit at the two ends of the 3d-wide qkv-bias slot."""
+    (g1, g2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b) = params[:11]
+    o = 6 * d
+    out = [(g1, 0), (g2, d), (n1w, 2 * d), (n1b, 3 * d), (n2w, 4 * d), (n2b, 5 * d), (qkv_w, o)]
+    o += 3 * d * d
+    out.append((proj_w, o))
+    o += d * d
+    out.append((proj_b, o))
+    o += d
+    out += [(q_bias, o), (v_bias, o + 2 * d)]
+    return out
+
+
+def expert_layout(params, d, hid):
+    w1, b1, w2, b2 = params
+    return [(w1, 0), (b1, hid * d), (w2, hid * d + hid), (b2, 2 * hid * d + hid)]
+
+
 def _fill_grads(D, flats, d, hid, nexp):
     """Parameter-gradient pointers of a VlmoBlockDesc from flat fp32 storage (flats[0]: shared parameters,
     flats[1 + e]: expert e) -> gradient tensors in BlockFn's parameter order."""
@@ -369,8 +389,10 @@ class BlockFn(torch.autograd.Function):
         exp_n = 2 * hid * d + hid + d
         if sink is not None:    # data-parallel run: accumulate straight into the reducer's persistent flat buckets
             akey, aroom = id(params[0]), shared_n + 3 * exp_n       # one arena per block: shared + up to 3 experts
-            flats = [sink.acquire(ctx.sink_groups[0], shared_n, dev, akey, aroom)] + \
-                    [sink.acquire(g_, exp_n, dev, akey, aroom) for g_ in ctx.sink_groups[1:]]
+            flats = [sink.acquire(ctx.sink_groups[0], shared_n, dev, akey, aroom,
+                                  layout=shared_layout(ctx.sink_groups[0], d))] + \
+                    [sink.acquire(g_, exp_n, dev, akey, aroom, layout=expert_layout(g_, d, hid))
+                     for g_ in ctx.sink_groups[1:]]
         else:                   # ONE zero-filled flat buffer (one memset) carved into all gradients of the block
             whole = torch.zeros(shared_n + nexp * exp_n, dtype=f32, device=dev)
             flats = [whole[:shared_n]] + [whole[shared_n + i * exp_n: shared_n + (i + 1) * exp_n] for i in range(nexp)]
@@ -563,8 +585,8 @@ class StackFn(torch.autograd.Function):
             if sink is not None:
                 akey, aroom = id(params[o]), shared_n + 3 * exp_n
                 groups = ctx.sink_groups[i]
-                flats = [sink.acquire(groups[0], shared_n, dev, akey, aroom)] + \
-                        [sink.acquire(g_, exp_n, dev, akey, aroom) for g_ in groups[1:]]
+                flats = [sink.acquire(groups[0], shared_n, dev, akey, aroom, layout=shared_layout(groups[0], d))] + \
+                        [sink.acquire(g_, exp_n, dev, akey, aroom, layout=expert_layout(g_, d, hid)) for g_ in groups[1:]]
             else:
                 flats = [whole[goff:goff + shared_n]]
                 goff += shared_n

@@ -121,7 +121,7 @@ def out_weights(mode, shape):
     return _normal(4242, 'R:' + mode, shape)
 
 
-def run_backbone_case(name, preset, B, with_grads=True, full_out=True, seed=0):
+def run_backbone_case(name, preset, B, with_grads=True, full_out=True, seed=0, full_grad_max=16384):
     from oracle import synth
     cfg = synth.make_config(preset)
     mc = cfg.model
@@ -166,7 +166,7 @@ def run_backbone_case(name, preset, B, with_grads=True, full_out=True, seed=0):
                 rec[f'{mode}.grad_norm.{k}'] = np.float64(g.double().norm().item())
                 rec[f'{mode}.grad_probe.{k}'] = np.float64(
                     (g.double() * grad_probe(k, g.shape).double()).sum().item())
-                if g.numel() <= 16384:
+                if g.numel() <= full_grad_max:
                     rec[f'{mode}.grad.{k}'] = g.numpy().astype(np.float32)
     # forward_interval (objectives.py:556-567 'fusion' MIM head position)
     xi = model.forward_interval(x=batch['image'], attn_masks=None, route='v', need_embed=True,
@@ -205,7 +205,7 @@ def run_dvae_case(name, B, res, seed=0, full_logits=True, **enc_kw):
     print(f'wrote {name}.npz')
 
 
-def run_module_case(name, preset, B, seed=0):
+def run_module_case(name, preset, B, seed=0, compact_logits=False):
     """Full VlmoModule.forward(batch) with [mlm, mim, itc, itm] (vlmo_module.py:395-436).
     Two call-argument level accommodations, arithmetic untouched:
     the dVAE pickles are absent, so objectives.create_d_vae is pointed at a Dalle_VAE whose
@@ -251,7 +251,13 @@ def run_module_case(name, preset, B, seed=0):
     rec = {'itm_img_neg_idx': np.array(drawn[:B]), 'itm_txt_neg_idx': np.array(drawn[B:2 * B])}
     total = 0
     for k, v in ret.items():
-        if torch.is_tensor(v):
+        if torch.is_tensor(v) and compact_logits and k in ('mlm_logits', 'mim_logits'):
+            # full-vocabulary logits are MBs: keep every 61st column, the row log-sum-exp and the arg-max
+            lg = v.detach().float()
+            rec['ret.' + k + '_sub'] = lg[:, ::61].numpy()
+            rec['ret.' + k + '_lse'] = torch.logsumexp(lg, 1).numpy()
+            rec['ret.' + k + '_argmax'] = lg.argmax(1).numpy()
+        elif torch.is_tensor(v):
             rec['ret.' + k] = v.detach().float().numpy() if v.is_floating_point() else v.detach().numpy()
         else:
             rec['ret.' + k] = np.float64(v)
@@ -275,14 +281,23 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, REF)
     _install_timm_standin()
-    run_backbone_case('backbone_mini', 'mini', B=3)
-    run_backbone_case('backbone_small', 'small', B=2)
-    run_backbone_case('backbone_debug', 'debug', B=2)
-    run_backbone_case('backbone_base_b2', 'base', B=2, full_out=False)
-    run_module_case('module_mini', 'mini', B=4)
-    run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512)
-    run_dvae_case('dvae_small', B=2, res=32, n_hid=256, vocab_size=1024)
-    run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False)
+    cases = {
+        'backbone_mini': lambda: run_backbone_case('backbone_mini', 'mini', B=3),
+        'backbone_small': lambda: run_backbone_case('backbone_small', 'small', B=2),
+        'backbone_debug': lambda: run_backbone_case('backbone_debug', 'debug', B=2),
+        'backbone_base_b2': lambda: run_backbone_case('backbone_base_b2', 'base', B=2, full_out=False),
+        # VLMo-Large (conf/model/vlmo_large.yaml:14-28: d=1024, L=24, h=16, F=12); the synthetic layer-scale stays
+        # 0.5 as in every fixture (the YAML's init_values 1e-5 would make every residual branch invisible)
+        'backbone_large_b2': lambda: run_backbone_case('backbone_large_b2', 'large', B=2, full_out=False, full_grad_max=1024),
+        'module_mini': lambda: run_module_case('module_mini', 'mini', B=4),
+        'module_base_b2': lambda: run_module_case('module_base_b2', 'base', B=2, compact_logits=True),
+        'dvae_tiny': lambda: run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512),
+        'dvae_small': lambda: run_dvae_case('dvae_small', B=2, res=32, n_hid=256, vocab_size=1024),
+        'dvae_full_b2': lambda: run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False),
+    }
+    want = sys.argv[1:] or list(cases)
+    for name in want:
+        cases[name]()
 
 
 if __name__ == '__main__':

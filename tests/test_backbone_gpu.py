@@ -49,7 +49,7 @@ def modes(mc, batch, B):
 
 
 @pytest.mark.parametrize('name,preset', [('backbone_mini', 'mini'), ('backbone_small', 'small'),
-                                         ('backbone_base_b2', 'base')])
+                                         ('backbone_base_b2', 'base'), ('backbone_large_b2', 'large')])
 def test_forward_backward_matches_reference(golden_dir, name, preset):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     B = int(g['meta.B'])
@@ -69,9 +69,11 @@ def test_forward_backward_matches_reference(golden_dir, name, preset):
             got = xc[:, ::17]
         err = (got - ref).abs()
         report.append((mode, err.max().item(), err.mean().item()))
-        atol = 2e-2 if mc.depth <= 3 else 3e-2
+        # error grows ~sqrt(depth): 2-3 layers 2e-2, Base (12) 3e-2, Large (24 layers, conf/model/vlmo_large.yaml) 4.5e-2
+        atol = 2e-2 if mc.depth <= 3 else (3e-2 if mc.depth <= 12 else 4.5e-2)
+        mean_tol = 4e-3 if mc.depth <= 12 else 6e-3
         assert (err <= atol + 2e-2 * ref.abs()).all(), f'{name}/{mode}: max err {err.max().item():.4f}'
-        assert err.mean().item() <= 4e-3, f'{name}/{mode}: mean err {err.mean().item():.5f}'
+        assert err.mean().item() <= mean_tol, f'{name}/{mode}: mean err {err.mean().item():.5f}'
         np.testing.assert_array_equal(m.cpu().numpy(), g[f'{mode}.mask'])
         pooled = model.pooler(x.detach()).detach().float().cpu().numpy()
         np.testing.assert_allclose(pooled, g[f'{mode}.pooled'], atol=2e-2, rtol=2e-2)

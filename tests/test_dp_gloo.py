@@ -301,3 +301,109 @@ def test_gather_layer_world2_gloo():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+def _zero_worker(rank, world, port, q):
+    """ZeRO-2 (conf/ds_stage/l2.yaml): reduce-scattered gradients -> sharded AdamW on this rank's slice ->
+    all-gather of the updated parameters must equal the REPLICATED step (every rank running torch.optim.AdamW on the
+    all-reduced gradients) parameter for parameter, with global-norm clipping, name-group lr / weight decay, an
+    engine-style sink bucket (with the hole the qkv bias leaves) beside the hook buckets.  On CPU the two device
+    kernels of ZeroAdam are replaced by their torch restatement (test infrastructure; the product path has none)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from exploremultimodal_amd.dp import GradReducer
+        from exploremultimodal_amd.zero import ZeroAdam
+
+        class CpuZero(ZeroAdam):
+            def _views(self, tab):
+                import ctypes
+                out = []
+                for (pp, gp, mp_, vp, n, gi) in tab['ent']:
+                    mk = lambda a: torch.frombuffer((ctypes.c_float * n).from_address(a), dtype=torch.float32)
+                    out.append((mk(pp), mk(gp), mk(mp_), mk(vp), gi))
+                return out
+
+            def _local_sqnorm(self, tab):
+                return sum((g.double() ** 2).sum() for _, g, _, _, _ in self._views(tab)).float()
+
+            def _apply(self, tab, a, ctl):
+                if ctl is not None and float(ctl[2]) != 0:
+                    return
+                gs = float(ctl[1]) if ctl is not None else 1.0
+                for p, g, m, v, gi in self._views(tab):
+                    grp = self.param_groups[gi]
+                    g = g * gs
+                    m.mul_(a.beta1).add_(g, alpha=1 - a.beta1)
+                    v.mul_(a.beta2).addcmul_(g, g, value=1 - a.beta2)
+                    u = (m * a.inv_bc1) / ((v * a.inv_bc2).sqrt() + a.eps) + grp['weight_decay'] * p
+                    p.sub_(grp['lr'] * u)
+
+        torch.manual_seed(5)
+        model, ref = Tiny(), Tiny()
+        ref.load_state_dict(model.state_dict())
+        red = GradReducer(model, reduce_scatter=True, engine_sink=False)
+        # block 1's linear goes through the engine-sink protocol with a hole in its flat layout
+        sink_lin = model.blocks[1]['a']
+        group = (sink_lin.weight, sink_lin.bias)
+        layout = [(sink_lin.weight, 0), (sink_lin.bias, sink_lin.weight.numel() + 7)]
+        sink_n = sink_lin.weight.numel() + 7 + sink_lin.bias.numel()
+        red._sink_params.update(id(p) for p in group)
+
+        def groups_of(m):
+            dec = [p for n, p in m.named_parameters() if p.dim() > 1]
+            nodec = [p for n, p in m.named_parameters() if p.dim() <= 1]
+            return [{'params': dec, 'lr': 3e-2, 'weight_decay': 0.1}, {'params': nodec, 'lr': 1e-2, 'weight_decay': 0.0}]
+        opt = CpuZero(red, groups_of(model), betas=(0.9, 0.98), eps=1e-5)    # well-conditioned m / (sqrt(v) + eps)
+        ropt = torch.optim.AdamW(groups_of(ref), betas=(0.9, 0.98), eps=1e-5)
+        for step in range(3):
+            g = torch.Generator().manual_seed(11 + rank + 10 * step)
+            x = torch.randn(6, 8, generator=g)
+            for m in (model, ref):
+                for p in m.parameters():
+                    p.grad = None
+            loss = model(x).square().mean()
+            red.prepare(loss)
+            loss.backward()
+            # hand block 1's gradients to the sink bucket as the engine would
+            flat = red.acquire(group, sink_n, torch.device('cpu'), layout=layout)
+            for p, off in layout:
+                flat[off:off + p.numel()] += p.grad.reshape(-1)
+                p.grad = None
+            red.release_all([group])
+            red.finish()
+            opt.step(clip_grad=0.5)
+            ref(x).square().mean().backward()
+            for p in ref.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad)
+                    p.grad /= world
+            torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], 0.5)
+            ropt.step()
+            for (n, p), pr in zip(model.named_parameters(), ref.parameters()):
+                if 'unused' in n:
+                    continue
+                assert torch.allclose(p.detach(), pr.detach(), rtol=1e-4, atol=5e-5), (step, n, (p - pr).abs().max())  # updates are lr-sized (3e-2): 5e-5 is fp32 summation-order noise through m / sqrt(v)
+        # the moments exist only for this rank's slices
+        total = sum(pt.padded for pt in opt.parts)
+        assert sum(pt.m.numel() for pt in opt.parts) * world == total
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero2_sharded_step_equals_replicated_step_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
