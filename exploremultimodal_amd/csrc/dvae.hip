@@ -77,7 +77,44 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const float* __restr
     ids[m] = bi;
 }
 
+// Finish of the fused cross-entropy forward (VLMO_EPI_CE): partial [M, nchunk, {max, sumexp, argmax, label logit}]
+// -> lse [M], per-row loss (0 where label == ignore), prediction [M]
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ part, int nchunk,
+                                                        const int32_t* __restrict__ labels, int ignore_index,
+                                                        float* __restrict__ lse, float* __restrict__ loss,
+                                                        int32_t* __restrict__ pred, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* p = part + (size_t)m * nchunk * 4;
+    float best = -INFINITY, labv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = 0; c < nchunk; ++c) {
+        const float v = p[4 * c];
+        const int idx = ((const int*)p)[4 * c + 2];
+        if (v > best || (v == best && idx < bi)) {
+            best = v;
+            bi = idx;
+        }
+        labv = fmaxf(labv, p[4 * c + 3]);
+    }
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += p[4 * c + 1] * __expf(p[4 * c] - best);
+    const float l = best + __logf(s);
+    lse[m] = l;
+    if (pred) pred[m] = bi;
+    if (loss) loss[m] = (labels[m] == ignore_index) ? 0.f : l - labv;
+}
+
 }  // namespace
+
+extern "C" int vlmo_ce_reduce(const float* partial, int nchunk, const int32_t* labels, int ignore_index, float* lse,
+                              float* loss, int32_t* pred, int M, hipStream_t stream) {
+    VLMO_CHECK_ARG(partial && labels && lse && M > 0 && nchunk > 0, "vlmo_ce_reduce: bad arguments");
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, partial, nchunk, labels,
+                       ignore_index, lse, loss, pred, M);
+    VLMO_CHECK_LAUNCH("vlmo_ce_reduce");
+    return 0;
+}
 
 extern "C" int vlmo_dvae_im2col(const float* x, void* out, int B, int C, int H, int W, int kw, int Kpad,
                                 hipStream_t stream) {

@@ -22,7 +22,8 @@
 
 namespace {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3, EPI_F32 = 4, EPI_DUAL = 5, EPI_ARGMAX = 6 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3, EPI_F32 = 4, EPI_DUAL = 5, EPI_ARGMAX = 6, EPI_CE = 7,
+       EPI_CE_BWD = 8 };
 
 struct GemmNT {
     const void* A;
@@ -123,6 +124,16 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gmb, int row, int
         if (e.out2)
             store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f),
                       fmaxf(v[3], 0.f));
+    } else if constexpr (EPI == EPI_CE_BWD) {
+        // d(cross-entropy)/d(logits) of row gm, recomputed from the logits instead of read back: (softmax - onehot) *
+        // row scale (heads.py:86-112 + objectives.py:57-68,571-582).  resid = lse [M], row_scale = dloss / n_valid per
+        // row (0 on ignored rows), row_index = labels [M]
+        const float lse = e.resid[gm], sc = e.row_scale[gm];
+        const int lab = e.row_index[gm];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = (__builtin_amdgcn_exp2f((v[j] - lse) * 1.4426950408889634f) - (gn + j == lab ? 1.f : 0.f)) * sc;
+        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(ext[j]);
@@ -441,6 +452,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                     float* pv = (float*)p.e.out + ((size_t)gm * p.e.ldo + chunk) * 2;
                     pv[0] = best;
                     ((int*)pv)[1] = bi;
+                }
+            } else if constexpr (EPI == EPI_CE) {
+                // fused cross-entropy forward: per row and 64-column chunk {max, sum exp(x - max), arg-max, logit of
+                // the row's label or -inf}; the [n, vocabulary] logits never reach HBM.  row_index = labels
+                f32x4 vv = v[it] + bias4;
+                const int lab = (gm < p.M) ? p.e.row_index[gm] : -1;
+                float best = -INFINITY, labv = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gn + j < p.N) {
+                        if (vv[j] > best) {
+                            best = vv[j];
+                            bi = gn + j;
+                        }
+                        if (gn + j == lab) labv = vv[j];
+                    }
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) {
+                    const float ob = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ob > best || (ob == best && oi < bi)) {
+                        best = ob;
+                        bi = oi;
+                    }
+                    labv = fmaxf(labv, __shfl_xor(labv, o, 64));
+                }
+                float se = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gn + j < p.N) se += __builtin_amdgcn_exp2f((vv[j] - best) * 1.4426950408889634f);
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) se += __shfl_xor(se, o, 64);
+                if ((lane % LPR) == 0 && gm < p.M) {
+                    const int chunk = (n0 + wn * (BN / WN)) / ROWF;
+                    float* pv = (float*)p.e.out + ((size_t)gm * p.e.ldo + chunk) * 4;
+                    pv[0] = best;
+                    pv[1] = se;
+                    ((int*)pv)[2] = bi;
+                    pv[3] = labv;
                 }
             } else {
                 if (gm < p.M && col_ok) epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it]);
@@ -799,6 +850,8 @@ int launch_nt(int epi, GemmNTGroups& p, hipStream_t st) {
                     VLMO_LAUNCH_EPI(EPI_RESID)
                     VLMO_LAUNCH_EPI(EPI_DGELU)
                     VLMO_LAUNCH_EPI(EPI_ARGMAX)
+                    VLMO_LAUNCH_EPI(EPI_CE)
+                    VLMO_LAUNCH_EPI(EPI_CE_BWD)
                     default:
                         known = false;
                 }
@@ -866,8 +919,8 @@ extern "C" int vlmo_profile_start(int max_records) {
     return 0;
 }
 
-// Stops recording and sums per tag (tag = epilogue id for gemm_nt, 32 + epilogue for conv, 64 for gemm_tn;
-// +8 when the 256x256 tile ran).  Call after the stream(s) have been synchronised.
+// Stops recording and sums per tag (tag = epilogue id for gemm_nt, +16 when the 256x256 tile ran; 32 + epilogue for
+// conv; 64 / 72 for gemm_tn 128x128 / 256x256, 73 for gemm_tn_multi).  Call after the stream(s) have been synchronised.
 extern "C" int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = false;
@@ -894,7 +947,9 @@ int check_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int
     VLMO_CHECK_ARG(K % 64 == 0, "vlmo_gemm_nt: K=%d must be a multiple of 64", K);
     VLMO_CHECK_ARG(N % 4 == 0, "vlmo_gemm_nt: N=%d must be a multiple of 4", N);
     VLMO_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "vlmo_gemm_nt: bad lda/ldb %d/%d", lda, ldb);
-    VLMO_CHECK_ARG(e->out && (epi == EPI_ARGMAX || (e->ldo >= N && e->ldo % 4 == 0)), "vlmo_gemm_nt: bad output / ldo");
+    VLMO_CHECK_ARG(e->out && (epi == EPI_ARGMAX || epi == EPI_CE || (e->ldo >= N && e->ldo % 4 == 0)), "vlmo_gemm_nt: bad output / ldo");
+    VLMO_CHECK_ARG(epi != EPI_CE || (e->ldo >= (N + 63) / 64 && e->row_index), "vlmo_gemm_nt: cross-entropy epilogue needs labels and ldo >= chunks");
+    VLMO_CHECK_ARG(epi != EPI_CE_BWD || (e->resid && e->row_scale && e->row_index), "vlmo_gemm_nt: cross-entropy backward needs lse, row scale, labels");
     VLMO_CHECK_ARG(epi != EPI_BIAS_GELU || (e->out2 && e->ld2 >= N), "vlmo_gemm_nt: gelu epilogue needs out2");
     VLMO_CHECK_ARG(epi != EPI_ARGMAX || e->ldo >= (N + 63) / 64, "vlmo_gemm_nt: argmax partial buffer too narrow");
     VLMO_CHECK_ARG(epi != EPI_RESID || e->resid, "vlmo_gemm_nt: residual epilogue needs resid");
@@ -914,7 +969,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         // stores overlap the other's MFMAs
         tile = (K >= 1536 && Mtot >= 2048 && N >= 512) ? 3 : 0;
     }
-    ProfScope prof(epi + (tile == 3 ? 8 : 0), 2.0 * Mtot * N * K, stream);
+    ProfScope prof(epi + (tile == 3 ? 16 : 0), 2.0 * Mtot * N * K, stream);
     VLMO_CHECK_ARG(tile == 0 || tile == 3, "vlmo_gemm_nt: tile must be -1, 0 or 3 (got %d)", tile);
     if (dtype == VLMO_F16) {
         if (tile == 3) return launch_nt<f16, 256, 256, 2, 4, false, 64, 2, true>(epi, gp, stream);
@@ -946,7 +1001,7 @@ extern "C" int vlmo_gemm_nt_grouped(int epi, int dtype, int tile, int ngroups, c
                                     const void* const* B, int ldb, const int32_t* M, int N, int K,
                                     const VlmoEpilogue* e, hipStream_t stream) {
     VLMO_CHECK_ARG(ngroups >= 1 && ngroups <= MAX_GROUPS && A && B && M && e, "vlmo_gemm_nt_grouped: 1..%d groups", MAX_GROUPS);
-    VLMO_CHECK_ARG(epi != EPI_ARGMAX, "vlmo_gemm_nt_grouped: the arg-max epilogue is single-problem");
+    VLMO_CHECK_ARG(epi != EPI_ARGMAX && epi != EPI_CE, "vlmo_gemm_nt_grouped: the arg-max / cross-entropy epilogues are single-problem");
 #ifdef VLMO_NO_GROUPING      // measurement aid: one launch per group
     for (int q = 0; q < ngroups; ++q)
         if (int rc = vlmo_gemm_nt(epi, dtype, tile, A[q], lda, B[q], ldb, M[q], N, K, &e[q], stream)) return rc;

@@ -1,9 +1,83 @@
 """Task heads of VlmoModule (models/vlmo/heads.py:86-138) with identical parameter names.
 
-Small GEMMs on a few thousand gathered rows; they run as stock torch ops on the device
-(bf16 autocast is the caller's choice).  SURVEY.md section 8f ranks fusing them next."""
+The two vocabulary heads -- the MLM decoder tied to the word embedding (768 -> 30 522) and the MIM head
+(768 -> 8 192 visual tokens) -- have a fused loss path (``loss_and_pred``): a HIP GEMM whose epilogue keeps per-row
+running (max, sum exp, arg-max, label logit) per 64-column chunk, so the [rows, vocabulary] logits never reach HBM, and
+a backward that recomputes (softmax - onehot) tile-wise into the bf16 operand of the input- and weight-gradient GEMMs
+(VLMO_EPI_CE / VLMO_EPI_CE_BWD, csrc/gemm.hip).  ``forward`` still returns the logits (reference contract:
+`mlm_logits` / `mim_logits` in the output dict); ``config.train.fused_ce`` selects the fused path in the objectives.
+The small heads (ITC projection + normalise, 2-way ITM, pooler) are a few MFLOP and stay torch ops."""
 import torch
 import torch.nn as nn
+
+from . import hip
+
+
+class _PaddedShadows:
+    """bf16 copies of a vocabulary head's weight padded to a multiple of 64 rows (W [Vp, d], W^T [d, Vp]) and its fp32
+    bias padded with -1e30 (so padded columns vanish from the soft-max), refreshed when a version counter changes."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, weight, bias):
+        key = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
+        if self.key != key:
+            V, d = weight.shape
+            Vp = (V + 63) // 64 * 64
+            w = torch.zeros((Vp, d), dtype=torch.bfloat16, device=weight.device)
+            w[:V] = weight.detach()
+            wt = w.t().contiguous()
+            b = torch.full((Vp,), -1e30, dtype=torch.float32, device=weight.device)
+            b[:V] = bias.detach() if bias is not None else 0.0
+            self.key, self.val = key, (w, wt, b, Vp)
+        return self.val
+
+
+class LinearCrossEntropyFn(torch.autograd.Function):
+    """mean cross-entropy of ``x @ W^T + b`` against ``labels`` (rows with ``ignore_index`` excluded) and the
+    arg-max prediction per row, without materialising the logits (heads.py:86-112 + objectives.py:57-68,571-582)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels, ignore_index, shadows):
+        n, d = x.shape
+        V = weight.shape[0]
+        w, wt, b, Vp = shadows.get(weight, bias)
+        xb = x.detach().to(torch.bfloat16).contiguous()
+        lab = labels.to(torch.int32).contiguous()
+        nch = Vp // 64
+        dev = x.device
+        part = torch.empty((n, nch, 4), dtype=torch.float32, device=dev)
+        hip.gemm_nt(hip.EPI_CE, xb, w, n, Vp, d, part, bias=b, row_index=lab, ldo=nch)
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        rows = torch.empty(n, dtype=torch.float32, device=dev)
+        pred = torch.empty(n, dtype=torch.int32, device=dev)
+        hip.ce_reduce(part, nch, lab, ignore_index, lse, rows, pred, n)
+        valid = labels != ignore_index
+        nvalid = valid.sum().clamp(min=1).to(torch.float32)
+        ctx.save_for_backward(xb, lab, lse, valid, nvalid, w, wt, b)
+        ctx.dims = (n, d, V, Vp, bias is not None)
+        ctx.mark_non_differentiable(pred)
+        return rows.sum() / nvalid, pred
+
+    @staticmethod
+    def backward(ctx, dloss, _dpred):
+        xb, lab, lse, valid, nvalid, w, wt, b = ctx.saved_tensors
+        n, d, V, Vp, has_bias = ctx.dims
+        dev = xb.device
+        rs = (valid.to(torch.float32) * (dloss.to(torch.float32) / nvalid)).contiguous()
+        dlog = torch.empty((n, Vp), dtype=torch.bfloat16, device=dev)
+        hip.gemm_nt(hip.EPI_CE_BWD, xb, w, n, Vp, d, dlog, bias=b, resid=lse, row_scale=rs, row_index=lab)
+        dx = torch.empty((n, d), dtype=torch.float32, device=dev)
+        hip.gemm_nt(hip.EPI_F32, dlog, wt, n, d, Vp, dx)
+        dw = torch.zeros((Vp, d), dtype=torch.float32, device=dev)
+        hip.gemm_tn(dlog, xb, dw, n, Vp, d)
+        db = None
+        if has_bias:
+            db = torch.zeros(Vp, dtype=torch.float32, device=dev)
+            hip.colsum(dlog, db, n, Vp)
+            db = db[:V]
+        return dx, dw[:V], db, None, None, None
 
 
 class BertPredictionHeadTransform(nn.Module):
@@ -32,6 +106,13 @@ class MLMHead(nn.Module):
     def forward(self, x):
         return self.decoder(self.transform(x)) + self.bias
 
+    def loss_and_pred(self, x, labels, ignore_index=-100):
+        """fused decoder + cross-entropy: (mean loss over rows whose label is not ignore_index, arg-max [n])."""
+        if not hasattr(self, '_ce_shadows'):
+            object.__setattr__(self, '_ce_shadows', _PaddedShadows())
+        return LinearCrossEntropyFn.apply(self.transform(x), self.decoder.weight, self.bias, labels, ignore_index,
+                                          self._ce_shadows)
+
 
 class MIMHead(nn.Module):
     """heads.py:104-112."""
@@ -42,6 +123,11 @@ class MIMHead(nn.Module):
 
     def forward(self, x):
         return self.fc(x)
+
+    def loss_and_pred(self, x, labels, ignore_index=-100):
+        if not hasattr(self, '_ce_shadows'):
+            object.__setattr__(self, '_ce_shadows', _PaddedShadows())
+        return LinearCrossEntropyFn.apply(x, self.fc.weight, self.fc.bias, labels, ignore_index, self._ce_shadows)
 
 
 class ITCHead(nn.Module):

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VLMO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvlmo_hip.so')
 
 BF16, F16, F32 = 0, 1, 2
-EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32, EPI_DUAL, EPI_ARGMAX = 0, 1, 2, 3, 4, 5, 6
+EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32, EPI_DUAL, EPI_ARGMAX, EPI_CE, EPI_CE_BWD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _vp, _i32, _u32, _u64, _f32, _i64 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
                                      ctypes.c_uint64, ctypes.c_float, ctypes.c_int64)
@@ -101,6 +101,7 @@ _SIGS = {
     'vlmo_dvae_im2col': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'vlmo_maxpool2_nhwc': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'vlmo_argmax_reduce': [_vp, _i32, _vp, _i32, _vp],
+    'vlmo_ce_reduce': [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     'vlmo_block_fwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_block_bwd': [ctypes.POINTER(BlockDesc), _vp],
     'vlmo_stack_fwd': [ctypes.POINTER(StackDesc), _vp],
@@ -419,6 +420,11 @@ def stack_bwd(sdesc):
     _check(lib().vlmo_stack_bwd(ctypes.byref(sdesc), _stream()), 'vlmo_stack_bwd')
 
 
+def ce_reduce(partial, nchunk, labels, ignore_index, lse, loss, pred, M):
+    _check(lib().vlmo_ce_reduce(_p(partial), nchunk, _p(labels), ignore_index, _p(lse), _p(loss), _p(pred), M, _stream()),
+           'vlmo_ce_reduce')
+
+
 def block_fwd(desc):
     _check(lib().vlmo_block_fwd(ctypes.byref(desc), _stream()), 'vlmo_block_fwd')
 
@@ -473,7 +479,7 @@ def profile_stop():
     n = PROFILE_TAGS
     ms, fl, ln = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
     lib().vlmo_profile_stop(n, ms, fl, ln)
-    names = {0: 'bias', 1: 'bias_gelu', 2: 'resid', 3: 'dgelu', 4: 'f32', 5: 'dual', 6: 'argmax'}
+    names = {0: 'bias', 1: 'bias_gelu', 2: 'resid', 3: 'dgelu', 4: 'f32', 5: 'dual', 6: 'argmax', 7: 'ce', 8: 'ce_bwd'}
     out = {}
     for t in range(n):
         if ln[t]:
@@ -484,6 +490,6 @@ def profile_stop():
             elif t >= 32:
                 name = f'conv_nt_kernel<{names.get(t - 32, t - 32)}>'
             else:
-                name = f'gemm_nt_kernel<{names.get(t & 7, t & 7)},{"256x256" if t & 8 else "128x128"}>'
+                name = f'gemm_nt_kernel<{names.get(t & 15, t & 15)},{"256x256" if t & 16 else "128x128"}>'
             out[name] = (ms[t] * 1e-3, fl[t], ln[t])
     return out

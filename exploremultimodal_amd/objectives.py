@@ -46,36 +46,43 @@ class GatherLayer(torch.autograd.Function):
 
 
 def compute_accuracy(logits, target):
-    """objectives.py:24-37."""
-    preds = logits.argmax(dim=-1)
-    preds = preds[target != -100]
-    target = target[target != -100]
-    if target.numel() == 0:
+    """objectives.py:24-37 -> (mean accuracy over labels != -100, their count)."""
+    keep = target != -100
+    n = int(keep.sum())
+    if n == 0:
         return torch.tensor(0, device=target.device), 0
-    assert preds.shape == target.shape
-    return (preds == target).float().mean(), target.numel()
+    return (logits.argmax(dim=-1)[keep] == target[keep]).float().mean(), n
+
+
+def _vocab_head_loss(model, head, feats, labels, vocab):
+    """Loss / logits / accuracy of a vocabulary head on gathered rows.  ``config.train.fused_ce``: HIP path without
+    logits in HBM (heads.LinearCrossEntropyFn; `*_logits` is then None); else the logits are returned as the
+    reference does (objectives.py:57-68, 571-582).  With no rows the loss is the python float 0."""
+    n = labels.numel()
+    fused = bool(getattr(model.config.train, 'fused_ce', False))
+    if n == 0:
+        return 0., (None if fused else head(feats)), torch.tensor(0, device=labels.device), 0
+    if fused:
+        loss, pred = head.loss_and_pred(feats, labels)
+        return loss, None, (pred.to(labels.dtype) == labels).float().mean(), n
+    logits = head(feats)
+    acc, cnt = compute_accuracy(logits, labels)
+    return F.cross_entropy(logits.view(-1, vocab), labels.view(-1), ignore_index=-100), logits, acc, cnt
 
 
 def compute_mlm(model, batch):
-    """objectives.py:40-78."""
-    has_img = any(['image' in k for k in batch.keys()])
+    """objectives.py:40-78: MLM head on the text positions whose label is not -100."""
     infer = batch.get('_mlm_infer')
     if infer is None:
-        infer = model.infer(batch, infer_mode='img-txt' if has_img else 'txt_only', mask_txt=True, mask_img=False)
-    txt_feats = infer['txt_feats']
-    mlm_labels = infer['txt_labels']
-    mask = (mlm_labels != -100).unsqueeze(-1).expand_as(txt_feats)
-    masked_txt_feats = txt_feats[mask].contiguous().view(-1, txt_feats.size(-1))
-    mlm_logits = model.mlm_head(masked_txt_feats)
-    mlm_labels = mlm_labels[mlm_labels != -100]
-    mlm_mean_acc, mlm_count = compute_accuracy(mlm_logits, mlm_labels)
-    if mlm_count > 0:
-        mlm_loss = F.cross_entropy(mlm_logits.view(-1, model.config.model.vocab_size), mlm_labels.view(-1),
-                                   ignore_index=-100)
-    else:
-        mlm_loss = 0.
-    return {'mlm_task_loss': mlm_loss, 'mlm_logits': mlm_logits, 'mlm_labels': mlm_labels,
-            'mlm_ids': infer['txt_ids'], 'mlm_mean_acc': mlm_mean_acc, 'mlm_count': mlm_count}
+        mode = 'img-txt' if any('image' in k for k in batch.keys()) else 'txt_only'
+        infer = model.infer(batch, infer_mode=mode, mask_txt=True, mask_img=False)
+    labels_all = infer['txt_labels']
+    picked = labels_all != -100
+    feats = infer['txt_feats'][picked].contiguous()          # [n_masked, d]
+    labels = labels_all[picked]
+    loss, logits, acc, cnt = _vocab_head_loss(model, model.mlm_head, feats, labels, model.config.model.vocab_size)
+    return {'mlm_task_loss': loss, 'mlm_logits': logits, 'mlm_labels': labels, 'mlm_ids': infer['txt_ids'],
+            'mlm_mean_acc': acc, 'mlm_count': cnt}
 
 
 def compute_itc(model, batch):
@@ -83,7 +90,9 @@ def compute_itc(model, batch):
     rank with GatherLayer, objectives.py:99-108); the momentum / queue branches (off in
     conf/train/pretrain_mum.yaml:39-42) are out of scope."""
     with torch.no_grad():
-        model.itc_temp.data = torch.clamp(model.itc_temp.data, 0, 4.6052)
+        # in place (same values as the reference's re-assignment of .data): the parameter keeps its storage, which the
+        # flat-buffer optimizers (FusedAdam's cached tables, zero.ZeroAdam's re-homed parameters) rely on
+        model.itc_temp.data.clamp_(0, 4.6052)
     temp = model.itc_temp.exp()
     if model.transformer_m is not None:
         raise NotImplementedError('the momentum ITC branch is out of scope (SURVEY.md 8f)')
@@ -183,13 +192,8 @@ def compute_mim(module, batch):
         infer = {'img_feats': img_feats}
     else:
         raise KeyError(f'unknown mim_head_pos {pos!r}')
-    patch_x = infer['img_feats'][:, 1:]
-    masked_patch_x = patch_x[bool_masked_pos].contiguous()
-    mim_logits = module.mim_head(masked_patch_x)
-    mim_mean_acc, mim_count = compute_accuracy(mim_logits, mim_labels)
-    if mim_count > 0:
-        mim_loss = F.cross_entropy(mim_logits.view(-1, module.config.model.img_vocab_size), mim_labels.view(-1))
-    else:
-        mim_loss = 0.
-    return {'mim_task_loss': mim_loss, 'mim_logits': mim_logits, 'mim_labels': mim_labels,
-            'mim_mean_acc': mim_mean_acc, 'mim_count': mim_count}
+    feats = infer['img_feats'][:, 1:][bool_masked_pos].contiguous()      # [n_masked, d] (patch tokens only)
+    loss, logits, acc, cnt = _vocab_head_loss(module, module.mim_head, feats, mim_labels,
+                                              module.config.model.img_vocab_size)
+    return {'mim_task_loss': loss, 'mim_logits': logits, 'mim_labels': mim_labels, 'mim_mean_acc': acc,
+            'mim_count': cnt}

@@ -43,8 +43,14 @@ enum {
     VLMO_EPI_DGELU = 3,     /* out[T]   = dropout_mask(acc) * gelu_erf'(aux[m,n])            */
     VLMO_EPI_F32 = 4,       /* out[f32] = acc + bias + beta * out                             */
     VLMO_EPI_DUAL = 5,      /* v = resid[T] + beta*(acc + bias); out[T] = v; out2[T] = relu(v)  */
-    VLMO_EPI_ARGMAX = 6     /* out = partial (max, argmax) of acc + bias per row and 64-column   */
+    VLMO_EPI_ARGMAX = 6,    /* out = partial (max, argmax) of acc + bias per row and 64-column   */
                             /* chunk: float/int32 pairs [M, ldo, 2]; finish with vlmo_argmax_reduce */
+    VLMO_EPI_CE = 7,        /* fused cross-entropy forward of a vocabulary head (heads.py:86-112,    */
+                            /* objectives.py:57-68,571-582): out = partial {max, sum exp(x - max),    */
+                            /* argmax, logit of label row_index[m]} per row and 64-column chunk,      */
+                            /* floats [M, ldo, 4]; finish with vlmo_ce_reduce.  No logits in HBM.     */
+    VLMO_EPI_CE_BWD = 8     /* out[T] = (exp(acc + bias - lse[m]) - [n == label[m]]) * row_scale[m]:  */
+                            /* d loss / d logits recomputed; resid = lse [M] (1-D!), row_index = labels */
 };
 
 typedef struct VlmoEpilogue {
@@ -200,8 +206,8 @@ int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, c
                        float inv_keep, uint64_t seed, hipStream_t stream);
 
 /* Optional timing of the GEMM launches with HIP event pairs on their launch stream (bench.py's roofline).
- * stop() sums per tag: tag = epilogue id (+8 for the 256x256 tile) for vlmo_gemm_nt, 32 + epilogue for
- * vlmo_conv2d_nhwc, 64 for vlmo_gemm_tn; returns the number of recorded launches. Synchronise first. */
+ * stop() sums per tag: tag = epilogue id (+16 for the 256x256 tile) for vlmo_gemm_nt, 32 + epilogue for
+ * vlmo_conv2d_nhwc, 64 / 72 for vlmo_gemm_tn (128x128 / 256x256 tiles), 73 for vlmo_gemm_tn_multi; returns the number of recorded launches. Synchronise first. */
 int vlmo_profile_start(int max_records);
 int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches);
 
@@ -330,6 +336,10 @@ int vlmo_dvae_im2col(const float* x, void* out, int B, int C, int H, int W, int 
 /* MaxPool2d(2) (encoder.py:85,95,105): raw pooled map + relu of it (relu may be NULL). */
 int vlmo_maxpool2_nhwc(const void* x, void* raw, void* relu, int B, int H, int W, int C,
                        hipStream_t stream);
+/* finish of VLMO_EPI_CE: partial [M, nchunk, 4] -> lse [M], loss [M] (lse - label logit; 0 where
+ * labels[m] == ignore_index; may be NULL), pred [M] (arg-max, first maximum wins; may be NULL). */
+int vlmo_ce_reduce(const float* partial, int nchunk, const int32_t* labels, int ignore_index, float* lse,
+                   float* loss, int32_t* pred, int M, hipStream_t stream);
 /* final step of Dalle_VAE.get_codebook_indices (modeling_discrete_vae.py:246-248):
  * partial [M, nchunk, 2] from VLMO_EPI_ARGMAX -> ids int64 [M] (first maximum wins). */
 int vlmo_argmax_reduce(const float* partial, int nchunk, int64_t* ids, int M, hipStream_t stream);

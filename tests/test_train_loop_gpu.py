@@ -165,7 +165,9 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
             red.close()
         for n in results[0]:
             a, b = results[0][n], results[1][n]
-            assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), (n, (a - b).abs().max().item())
+            # the two runs' gradients differ by fp32 summation order (atomics in the column sums, embedding scatter):
+            # Adam turns that into up to a few % of one update (lr 1e-3 .. 5e-3) on near-zero-gradient elements
+            assert torch.allclose(a, b, rtol=1e-4, atol=2.5e-4), (n, (a - b).abs().max().item())
     finally:
         for r in reds:
             r.close()
