@@ -46,6 +46,20 @@ class Conv2d(nn.Module):
         self.b = nn.Parameter(b, requires_grad=requires_grad)
         self._shadow = None
 
+    def shadow_split(self):
+        """use_float16=False layers (the output conv, dall_e/encoder.py:116-119 + dall_e/utils.py:37-48: fp32 weights
+        on fp32 activations): the fp32 weight as TWO fp16 matrices side by side, [w_hi | w_lo] with w_hi = fp16(w) and
+        w_lo = fp16(w - w_hi) (~22 significant bits together), multiplied against the activations repeated twice
+        along K.  The fp16 MFMA products are exact in the fp32 accumulator, so the arg-max-deciding logits see the
+        reference's weight precision, not a 11-bit rounding of it."""
+        ver = (self.w._version, self.w.data_ptr(), 'split')
+        if self._shadow is None or self._shadow[0] != ver:
+            w = self.w.detach().permute(0, 2, 3, 1).reshape(self.n_out, -1).float()
+            hi = w.to(torch.float16)
+            lo = (w - hi.float()).to(torch.float16)
+            self._shadow = (ver, torch.cat([hi, lo], 1).contiguous(), self.b.detach().float().contiguous())
+        return self._shadow[1], self._shadow[2]
+
     def shadow(self):
         """fp16 weight in the engine's layout [n_out, kw*kw*n_in] (tap-major, channel-minor; the 3-channel
         stem keeps (c, ky, kx) order and is zero-padded to a multiple of 64 columns)."""
@@ -175,7 +189,8 @@ class Encoder(nn.Module):
     def forward(self, x):
         """encoder.py:123-133 -> logits fp32 [B, vocab, H/8, W/8]."""
         rel, (B, h, w) = self._features(x)
-        wo, bo = self.blocks.output.conv.shadow()
+        wo, bo = self.blocks.output.conv.shadow_split()
+        rel = torch.cat([rel, rel], 1)          # [x | x] against [w_hi | w_lo]
         M = rel.shape[0]
         logits = torch.empty((M, self.vocab_size), dtype=torch.float32, device=x.device)
         hip.gemm_nt(hip.EPI_F32, rel, wo, M, self.vocab_size, rel.shape[1], logits, bias=bo)
@@ -184,7 +199,8 @@ class Encoder(nn.Module):
     def codebook_indices(self, x):
         """argmax(forward(x), dim=1) without materialising the logits -> int64 [B, H/8, W/8]."""
         rel, (B, h, w) = self._features(x)
-        wo, bo = self.blocks.output.conv.shadow()
+        wo, bo = self.blocks.output.conv.shadow_split()
+        rel = torch.cat([rel, rel], 1)
         M = rel.shape[0]
         nchunk = (self.vocab_size + 63) // 64
         part = torch.empty((M, nchunk, 2), dtype=torch.float32, device=x.device)

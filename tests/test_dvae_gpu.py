@@ -132,7 +132,12 @@ def test_encoder_full_ids_vs_reference(golden_dir):
     gaps = g['top2_gap']
     print('dvae_full: id agreement', 1 - diff.mean(), 'max gap among mismatches', gaps[diff].max() if diff.any() else 0,
           'median top-2 gap', np.median(gaps))
-    assert 1 - diff.mean() >= 0.97
+    # gap histogram of the reference's top-2 logits: all positions vs the positions where the ids differ (SURVEY 8c:
+    # >= 99 % exact, every mismatch a near-tie below the fp16 activation resolution)
+    edges = [0, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 1e9]
+    print('top-2 gap histogram (edges', edges[:-1], '): all', np.histogram(gaps, edges)[0].tolist(),
+          'mismatched', np.histogram(gaps[diff], edges)[0].tolist())
+    assert 1 - diff.mean() >= 0.99
     assert (gaps[diff] < 3e-2).all()
     lm = enc(x).amax(1).cpu().numpy()
     assert np.abs(lm - g['logits_max']).max() <= 3e-2
