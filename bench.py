@@ -130,6 +130,7 @@ def main():
                     help='also run the fused AdamW step with global-norm clip 5.0 (conf/train/pretrain_mum.yaml:28-36,54,75-80) '
                          'inside the timed step; the headline metric is forward+backward only, so this is off by default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--logits', action='store_true', help='full objective: materialise mlm/mim logits as the reference does')
     ap.add_argument('--no-dropout', action='store_true')
     ap.add_argument('--force-reducer', action='store_true', help='run the RCCL gradient reducer even at world size 1')
     ap.add_argument('--objective', default='vl', choices=['vl', 'full'],
@@ -171,6 +172,7 @@ def main():
         cfg = synth.make_config(args.preset, loss_names=['mlm', 'mim', 'itc', 'itm'], drop_rate=drop,
                                 attn_drop_rate=drop, drop_path_rate=drop)
         cfg.train.merge_passes = args.merge_passes
+        cfg.train.fused_ce = not args.logits       # vocabulary heads: fused HIP cross-entropy, no logits in HBM
         torch.manual_seed(0)
         model, mc = build_module(cfg).to(dev), cfg.model
     else:

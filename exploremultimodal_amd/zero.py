@@ -103,7 +103,15 @@ class ZeroAdam:
             shard = getattr(pt.bucket, 'shard32', None)
             if shard is None:
                 continue            # this bucket has never been reduced (its parameters got no gradient yet)
+            # parameters of a hook bucket that received no gradient in this step (an objective skipped; unused heads)
+            # are left alone, as torch.optim / FusedAdam skip `grad is None` (no moment decay, no weight decay)
+            had = getattr(pt.bucket, 'had', None)
+            skip = set()
+            if had is not None:
+                skip = {id(p) for p, h in zip(pt.bucket.params, had) if not h}
             for p, off, gi in pt.entries:
+                if id(p) in skip:
+                    continue
                 lo, hi = max(off, pt.lo), min(off + p.numel(), pt.hi)
                 if lo >= hi:
                     continue
