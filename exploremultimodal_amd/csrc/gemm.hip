@@ -213,22 +213,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     for (int q = 1; q < MAX_GROUPS; ++q)
         if (q < gp.ngroups && lid_all >= gp.t0[q]) gi = q;
     gi = __builtin_amdgcn_readfirstlane(gi);
+    // (measured A/B in one session: the hoist is neutral-to-better for every epilogue except the GELU-derivative one,
+    // whose register allocation it hurts: dgrad_fc2 126 -> 135 us; that kernel keeps the kernarg reference)
+    const GemmNT& gq = gp.g[gi];
+    GemmNT pl;
+    const GemmNT* pp = &gq;
+    if constexpr (EPI != EPI_DGELU) {
     // the chosen problem, copied into SGPRs ONCE (see uniform_i): a dynamically indexed kernarg struct is
     // otherwise re-read with s_load + s_waitcnt at every use (115 scalar loads in the fc1 epilogue before this)
-    const GemmNT& gq = gp.g[gi];
-    GemmNT p;
-    p.A = uniform_ptr(gq.A), p.B = uniform_ptr(gq.B), p.zero = uniform_ptr(gq.zero);
-    p.M = uniform_i(gq.M), p.N = uniform_i(gq.N), p.K = uniform_i(gq.K), p.lda = uniform_i(gq.lda), p.ldb = uniform_i(gq.ldb);
-    p.cH = uniform_i(gq.cH), p.cW = uniform_i(gq.cW), p.cCin = uniform_i(gq.cCin), p.ckw = uniform_i(gq.ckw);
-    p.group_m = uniform_i(gq.group_m);
-    p.e.out = (void*)uniform_ptr(gq.e.out), p.e.out2 = (void*)uniform_ptr(gq.e.out2);
-    p.e.bias = (const float*)uniform_ptr(gq.e.bias), p.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
-    p.e.resid = (const float*)uniform_ptr(gq.e.resid), p.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
-    p.e.row_index = (const int32_t*)uniform_ptr(gq.e.row_index), p.e.aux = uniform_ptr(gq.e.aux);
-    p.e.ldo = uniform_i(gq.e.ldo), p.e.ld2 = uniform_i(gq.e.ld2), p.e.relu = uniform_i(gq.e.relu);
-    p.e.drop_thresh = (uint32_t)uniform_i((int)gq.e.drop_thresh);
-    p.e.inv_keep = uniform_f(gq.e.inv_keep), p.e.beta = uniform_f(gq.e.beta);
-    p.e.seed = (uint64_t)uniform_ptr((const void*)gq.e.seed);
+        pl.A = uniform_ptr(gq.A), pl.B = uniform_ptr(gq.B), pl.zero = uniform_ptr(gq.zero);
+        pl.M = uniform_i(gq.M), pl.N = uniform_i(gq.N), pl.K = uniform_i(gq.K), pl.lda = uniform_i(gq.lda), pl.ldb = uniform_i(gq.ldb);
+        pl.cH = uniform_i(gq.cH), pl.cW = uniform_i(gq.cW), pl.cCin = uniform_i(gq.cCin), pl.ckw = uniform_i(gq.ckw);
+        pl.group_m = uniform_i(gq.group_m);
+        pl.e.out = (void*)uniform_ptr(gq.e.out), pl.e.out2 = (void*)uniform_ptr(gq.e.out2);
+        pl.e.bias = (const float*)uniform_ptr(gq.e.bias), pl.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
+        pl.e.resid = (const float*)uniform_ptr(gq.e.resid), pl.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
+        pl.e.row_index = (const int32_t*)uniform_ptr(gq.e.row_index), pl.e.aux = uniform_ptr(gq.e.aux);
+        pl.e.ldo = uniform_i(gq.e.ldo), pl.e.ld2 = uniform_i(gq.e.ld2), pl.e.relu = uniform_i(gq.e.relu);
+        pl.e.drop_thresh = (uint32_t)uniform_i((int)gq.e.drop_thresh);
+        pl.e.inv_keep = uniform_f(gq.e.inv_keep), pl.e.beta = uniform_f(gq.e.beta);
+        pl.e.seed = (uint64_t)uniform_ptr((const void*)gq.e.seed);
+        pp = &pl;
+    }
+    const GemmNT& p = *pp;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int lid = lid_all - uniform_i(gp.t0[gi]);
     // grouped order: the ~64 tiles an XCD works on at once form a compact group_m x (64/group_m)
@@ -517,9 +524,9 @@ struct GemmTN {
 };
 enum { TN_ATOMIC = 0, TN_ACCUM = 1, TN_STORE = 2 };
 
-#ifndef TN_PREFETCH_DIST
-#define TN_PREFETCH_DIST 0
-#endif
+// 256 zero bytes: the staging source of token rows past the end of the reduction dimension
+__device__ __attribute__((aligned(256))) char tn_zero_page[256];
+
 // dual-use 256-byte-row image: chunk swizzle serving the transposed reads
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -570,8 +577,11 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
         char* s = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int gr = min(kt * 64 + a_row[i], p.M - 1);
-            glds16((const T*)p.A + (size_t)gr * p.lda + a_off[i], s + (i * NW + wave) * 1024);
+            // token rows past M (ragged last K-tile) are staged from a zero page: operand A is then exactly zero
+            // there, so the K loop needs no masking (B keeps the clamped last row; 0 * finite = 0)
+            const int gr = kt * 64 + a_row[i];
+            const T* src = gr < p.M ? (const T*)p.A + (size_t)gr * p.lda + a_off[i] : (const T*)tn_zero_page;
+            glds16(src, s + (i * NW + wave) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
@@ -594,35 +604,61 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
     const int ncol_a = wm * (BM / WM) + 16 * (g & 1) + 4 * pp;   // + tile*32
     const int ncol_b = wn * (BN / WN) + 16 * (g & 1) + 4 * pp;
 
-    // fragments of one 16-row k-step ks of the K-tile in image s_ (rows >= M were loaded from the clamped
-    // last row: one operand is zeroed there)
+    // LDS byte offsets of this lane's transposed reads inside a K-tile image, loop-invariant: the k-step enters
+    // additively (16 rows = 4096 B: an immediate offset of the ds_read), only (half, t) need their own register
+    // because the chunk swizzle is an XOR.  tn_swz(16 ks + m0) == tn_swz(m0).
+    int a_rd[2][TM], b_rd[2][TN];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int m0 = 8 * h + 4 * half + q;
+        const int sw = tn_swz(m0);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int na = ncol_a + t * 32;
+            a_rd[half][t] = (na >> 7) * SUB + m0 * 256 + ((((na & 127) >> 3) ^ sw) << 4) + (na & 7) * 2;
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int nb = ncol_b + t * 32;
+            b_rd[half][t] = A_BYTES + (nb >> 7) * SUB + m0 * 256 + ((((nb & 127) >> 3) ^ sw) << 4) + (nb & 7) * 2;
+        }
+    }
+    // fragments of one 16-row k-step ks of the K-tile in image s_.
+    // In the ping-pong schedule the transposed reads are INLINE ASM: behind the ds_read_tr builtin hipcc (ROCm 7.2)
+    // waits `vmcnt(0)` for every LDS-DMA in flight (the builtin carries no memory operand, so the waitcnt pass
+    // assumes it reads what the DMA writes), which put the whole HBM latency of the next K-tile's staging in front
+    // of the second read segment of every tile (2.3-3.0 us per K-tile where the plain-load NT kernel takes 1.7).
+    // The schedule orders DMA and reads itself (counted vmcnt + barriers); the reads' results are consumed only
+    // behind bar() = lgkmcnt(0) + s_barrier + sched_barrier.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    auto tr_read = [&](const char* s_, int off, int imm) -> v4 {
+        if constexpr (PP) {
+            typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+            u32x2 r;
+            const uint32_t addr = lds0 + (uint32_t)(s_ - smem) + (uint32_t)off;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(imm));
+            return __builtin_bit_cast(v4, r);
+        } else {
+            return lds_tr4<T>(s_ + off + imm);
+        }
+    };
     auto read_step = [&](const char* s_, int kt, int ks, v8* af, v8* bf) {
+        (void)kt;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int m = 16 * ks + 8 * h + 4 * half + q;
-            const int sw = tn_swz(m);
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                const int na = ncol_a + t * 32;
-                const v4 va = lds_tr4<T>(s_ + (na >> 7) * SUB + m * 256 + ((((na & 127) >> 3) ^ sw) << 4) + (na & 7) * 2);
+                const v4 va = ks == 0 ? tr_read(s_, a_rd[half][t], 0) : ks == 1 ? tr_read(s_, a_rd[half][t], 4096)
+                            : ks == 2 ? tr_read(s_, a_rd[half][t], 8192) : tr_read(s_, a_rd[half][t], 12288);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) af[t][4 * half + e] = va[e];
             }
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
-                const int nb = ncol_b + t * 32;
-                const v4 vb = lds_tr4<T>(s_ + A_BYTES + (nb >> 7) * SUB + m * 256 + ((((nb & 127) >> 3) ^ sw) << 4) + (nb & 7) * 2);
+                const v4 vb = ks == 0 ? tr_read(s_, b_rd[half][t], 0) : ks == 1 ? tr_read(s_, b_rd[half][t], 4096)
+                            : ks == 2 ? tr_read(s_, b_rd[half][t], 8192) : tr_read(s_, b_rd[half][t], 12288);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bf[t][4 * half + e] = vb[e];
-            }
-        }
-        if (kt * 64 + 64 > p.M) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool ok = (kt * 64 + 16 * ks + 8 * h + e) < p.M;
-#pragma unroll
-                for (int t = 0; t < TM; ++t)
-                    if (!ok) af[t][e] = (T)0.f;
             }
         }
     };
@@ -647,54 +683,68 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
-        // L2 prefetch: both operands are activations streamed ONCE from HBM (a K-tile of this workgroup is 512
-        // lines of 128 B), and the two-buffer ring keeps one K-tile (64 KB per CU) in flight, which covers an L2
-        // hit but not an HBM miss.  Every lane touches one line of K-tile kt + PD with a 4-byte LDS-DMA into a
-        // dummy LDS area (no VGPR destination: nothing to keep live); it is issued right after the real DMA
-        // of the iteration, so the counted `vmcnt(1)` below still retires every real DMA (loads return in order).
-        constexpr int PD = TN_PREFETCH_DIST;
-        char* pf_dst = smem + 2 * STAGE + wave * 256;
-        const int pf_idx = wave * 64 + lane;            // 0..511 with NW == 8
-        const int pf_op = (pf_idx >> 8) & 1, pf_row = (pf_idx >> 2) & 63, pf_seg = pf_idx & 3;
-        const T* pf_base = pf_op ? (const T*)p.B + min(n2_0 + pf_seg * 64, p.N2 - 8)
-                                 : (const T*)p.A + min(n1_0 + pf_seg * 64, p.N1 - 8);
-        const int pf_ld = pf_op ? p.ldb : p.lda;
-        auto prefetch = [&](int kt) {
-            const int gr = min(kt * 64 + pf_row, p.M - 1);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pf_base + (size_t)gr * pf_ld), LDS_PTR(pf_dst), 4, 0, 0);
+        // Half-tile staging, 1.5 K-tiles in flight.  Both operands are activations streamed once from HBM, and a
+        // K-tile's LDS-DMA is complete only when its slowest line has arrived: with ONE tile (64 KB per CU) in flight
+        // behind the tile being multiplied the loop runs at (loaded HBM latency) per K-tile -- 3.0 us in the training
+        // step where the matrix pipe needs 1.0 (rocprofv3, serial step: 788 us for 261 K-tiles).  The image of a
+        // K-tile is two independent halves (token rows 0-31 = k-steps 0,1 and rows 32-63 = k-steps 2,3; a wave's DMA
+        // instructions alternate between them), so each half is re-filled as soon as BOTH wave groups have read it:
+        //   tile kt, after barrier #4 of tile kt-1 : H1(kt+1) -> other buffer, rows 32-63 (tile kt-1 is done with them)
+        //   tile kt, after barrier #2              : H0(kt+2) -> this buffer, rows 0-31  (tile kt is done with them)
+        // Every half now has 1.5 tile times to land instead of < 1, and the waits are COUNTED (LDS-DMA completes in
+        // issue order): before the barrier that opens a half for reading a wave leaves exactly the younger halves it
+        // has issued since outstanding (4 DMA instructions per half and wave).
+        static_assert(NW == 8 && IA % 2 == 0 && IB % 2 == 0, "half-tile staging: 8 waves, even instruction counts");
+        auto stage_half = [&](int buf, int kt, int hf) {
+            char* s = smem + buf * STAGE;
+#pragma unroll
+            for (int i = 0; i < IA; ++i)
+                if ((i & 1) == hf) {       // instruction (i * 8 + wave): rows 4 * ((i * 8 + wave) & 15) ..+3 -> half (i & 1)
+                    const int gr = kt * 64 + a_row[i];
+                    const T* src = gr < p.M ? (const T*)p.A + (size_t)gr * p.lda + a_off[i] : (const T*)tn_zero_page;
+                    glds16(src, s + (i * NW + wave) * 1024);
+                }
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+                if ((i & 1) == hf) {
+                    const int gr = min(kt * 64 + b_row[i], p.M - 1);
+                    glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
+                }
         };
-        const bool pf_on = PD > 0 && NW == 8 && BM == 256 && BN == 256;
+        constexpr int PER_HALF = (IA + IB) / 2;
+        auto wait_leaving = [&](int halves) {       // s_waitcnt vmcnt(halves * PER_HALF), halves wave-uniform in 0..2
+            static_assert(PER_HALF == 4, "counted waits are written for 4 DMA instructions per half");
+            if (halves >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (halves == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
         stage(0, kt0);
-        if (pf_on)
-            for (int q = 1; q < PD; ++q)
-                if (kt0 + q < kt1) prefetch(kt0 + q);
+        if (kt0 + 1 < kt1) stage_half(1, kt0 + 1, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) bar();
         for (int kt = kt0; kt < kt1; ++kt) {
-            const char* cur = smem + ((kt - kt0) & 1) * STAGE;
-            const bool more = kt + 1 < kt1;
+            const int cb = (kt - kt0) & 1;
+            const char* cur = smem + cb * STAGE;
+            const bool n1 = kt + 1 < kt1, n2 = kt + 2 < kt1;
+            if (n1) stage_half(cb ^ 1, kt + 1, 1);                 // H1(kt+1)
             read_step(cur, kt, 0, af[0], bf[0]);
             read_step(cur, kt, 1, af[1], bf[1]);
-            bar();
-            if (more) stage((kt - kt0 + 1) & 1, kt + 1);
-            const bool pf = pf_on && kt + PD < kt1;
-            if (pf) prefetch(kt + PD);
+            // H1(kt) (read after the barrier two below / one below) is older than H0(kt+1), H1(kt+1)
+            if (wm == 1) wait_leaving(n1 ? 2 : 0);
+            bar();                                                  // #1
             mfma_half();
-            bar();
+            if (wm == 0) wait_leaving(n1 ? 2 : 0);
+            bar();                                                  // #2: both groups are done with rows 0-31
+            if (n2) stage_half(cb, kt + 2, 0);                      // H0(kt+2)
             read_step(cur, kt, 2, af[0], bf[0]);
             read_step(cur, kt, 3, af[1], bf[1]);
-            if (more && wm == 1) {
-                if (pf) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            bar();
+            // H0(kt+1) (read at the start of the next tile) is older than H1(kt+1), H0(kt+2)
+            if (wm == 1 && n1) wait_leaving(n2 ? 2 : 1);
+            bar();                                                  // #3
             mfma_half();
-            if (more && wm == 0) {
-                if (pf) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            bar();
+            if (wm == 0 && n1) wait_leaving(n2 ? 2 : 1);
+            bar();                                                  // #4: both groups are done with rows 32-63
         }
         if (wm == 0) bar();
     } else {
@@ -1075,7 +1125,7 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     dim3 grid(pl.tiles * pl.splits);
     ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
     if (pl.big) {
-        constexpr int LDS = 2 * 4 * 64 * 256 + 2048;
+        constexpr int LDS = 2 * 4 * 64 * 256;
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1110,7 +1160,7 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn_multi: dtype must be bf16 or f16");
     static bool attr = false;
     if (!attr) {
-        constexpr int LDS = 2 * 4 * 64 * 256 + 2048;
+        constexpr int LDS = 2 * 4 * 64 * 256;
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
@@ -1169,7 +1219,7 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         }
         for (int q = nq; q <= MAX_TN_PROBS; ++q) mp.t0[q] = t;
         ProfScope prof(73, flops, stream);
-        constexpr int LDS = 2 * 4 * 64 * 256 + 2048;
+        constexpr int LDS = 2 * 4 * 64 * 256;
         if (dtype == VLMO_F16)
             hipLaunchKernelGGL(gemm_tn_multi_kernel<f16>, dim3(t), dim3(512), LDS, stream, mp);
         else

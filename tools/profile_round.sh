@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): the bench plus the rocprofv3 passes whose summaries are committed under
+# profiles/.  usage: bash tools/profile_round.sh r02 [extra bench args]
+# Each pass is its own run of the same command; PMC passes carry only --kernel-trace beside --pmc.
+set -e
+TAG=$1; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp && cd $ROOT
+K=10; W=3; TOTAL=$((K + W + 3))       # bench.py runs W warm-up + K timed + 3 host-timing steps
+python3 bench.py --steps 40 --warmup 10 "$@" > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done" >> $OUT/progress.txt
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline "$@" > $OUT/stats.log 2>&1
+echo "stats done" >> $OUT/progress.txt
+for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o c --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline "$@" > $OUT/$C.log 2>&1
+  echo "$C done" >> $OUT/progress.txt
+done
+MS=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['ms_per_step'])")
+python3 tools/summarize_pmc.py $TAG $TOTAL $MS --stats $OUT/stats/s_kernel_stats.csv --fetch $OUT/FETCH_SIZE/c_counter_collection.csv \
+    --write $OUT/WRITE_SIZE/c_counter_collection.csv --mfma $OUT/SQ_VALU_MFMA_BUSY_CYCLES/c_counter_collection.csv --out $OUT
+cp $OUT/stats/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
+python3 tools/summarize_profile.py $OUT/stats/s_kernel_stats.csv $TOTAL > $OUT/${TAG}_summary.json
+cp $OUT/bench.json $OUT/${TAG}_bench.json
+ls -la $OUT | tail -20
