@@ -436,9 +436,23 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     }
 }
 
+// dynamic-LDS limit already raised for a kernel on a device (a process may drive several GPUs)
+int& lds_limit_set(int which) {
+    static int lim[2][64];
+    static bool init = false;
+    if (!init) {
+        for (auto& r : lim)
+            for (int& v : r) v = 65536;
+        init = true;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return lim[which][dev & 63];
+}
+
 int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     const int LDS = nt * 32 * 256 + nt * 32 * 8;
-    static int max_set = 65536;
+    int& max_set = lds_limit_set(0);
     if (LDS > max_set) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         max_set = LDS;
@@ -448,7 +462,7 @@ int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
 }
 int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     const int LDS = nt * 32 * 512 + nt * 32 * 16 + 16;
-    static int max_set = 65536;
+    int& max_set = lds_limit_set(1);
     if (LDS > max_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         max_set = LDS;

@@ -89,9 +89,24 @@ class _SinkBucket:
         self.shard = None
 
 
+def _all_reduce(comm, pg, world, rs_ag):
+    """Average-ready sum of a flat bucket over the ranks.  rs_ag (VLMO_DP_COLLECTIVE=rs_ag): the same result as a
+    reduce-scatter + all-gather pair on the bucket in place (what a ring all-reduce is made of, issued as the two
+    collectives RCCL schedules over all xGMI links) -- an A/B switch for the first multi-GPU run."""
+    if rs_ag and world > 1 and comm.numel() % world == 0:
+        n = comm.numel() // world
+        rank = dist.get_rank(pg)
+        mine = comm[rank * n:(rank + 1) * n]
+        dist.reduce_scatter_tensor(mine, comm, group=pg)
+        return dist.all_gather_into_tensor(comm, mine, group=pg, async_op=True)
+    return dist.all_reduce(comm, group=pg, async_op=True)
+
+
 class GradReducer:
     def __init__(self, module, process_group=None, comm_dtype=torch.bfloat16, reduce_scatter=False,
                  broadcast_params=True, engine_sink=True):
+        import os
+        self.rs_ag = os.environ.get('VLMO_DP_COLLECTIVE', 'all_reduce') == 'rs_ag'
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
         self.rank = dist.get_rank(self.pg)
@@ -286,7 +301,7 @@ class GradReducer:
                 torch.mul(flat, 1.0 / self.world, out=comm)
             else:
                 flat.mul_(1.0 / self.world)
-            work = dist.all_reduce(comm, group=self.pg, async_op=True)
+            work = _all_reduce(comm, self.pg, self.world, self.rs_ag)
             work.wait()
             if comm.data_ptr() != flat.data_ptr():
                 flat.copy_(comm)
@@ -317,7 +332,7 @@ class GradReducer:
                         n, dtype=torch.float32, device=self.device)
                 sb.work = dist.reduce_scatter_tensor(sb.shard_comm, sb.comm, group=self.pg, async_op=True)
             else:
-                sb.work = dist.all_reduce(sb.comm, group=self.pg, async_op=True)
+                sb.work = _all_reduce(sb.comm, self.pg, self.world, self.rs_ag)
             if self.on_gpu:
                 # the unpack follows its collective on the communication stream (work.wait() orders this stream
                 # after the collective, it does not block the host): it overlaps the rest of the backward pass
@@ -372,7 +387,7 @@ class GradReducer:
                         n, dtype=torch.float32, device=self.device)
                 b.work = dist.reduce_scatter_tensor(b.shard_comm, b.comm, group=self.pg, async_op=True)
             else:
-                b.work = dist.all_reduce(b.comm, group=self.pg, async_op=True)
+                b.work = _all_reduce(b.comm, self.pg, self.world, self.rs_ag)
             if self.on_gpu:
                 b.work.wait()           # orders the communication stream after the collective (no host block)
                 self._unpack(b)

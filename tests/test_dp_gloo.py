@@ -235,8 +235,13 @@ def test_engine_sink_protocol_world2_gloo():
         assert msg == 'ok', f'rank {rank}: {msg}'
 
 
-@pytest.mark.parametrize('mode', ['allreduce', 'rs'])
-def test_grad_reducer_world2_gloo(mode):
+@pytest.mark.parametrize('mode', ['allreduce', 'rs', 'rs_ag'])
+def test_grad_reducer_world2_gloo(mode, monkeypatch):
+    """rs_ag: VLMO_DP_COLLECTIVE=rs_ag replaces every all-reduce by reduce-scatter + all-gather on the bucket in
+    place (the A/B switch for the first multi-GPU run): same averaged gradients."""
+    if mode == 'rs_ag':
+        monkeypatch.setenv('VLMO_DP_COLLECTIVE', 'rs_ag')
+        mode = 'allreduce'
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
