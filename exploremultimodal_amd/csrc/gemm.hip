@@ -683,68 +683,31 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
-        // Half-tile staging, 1.5 K-tiles in flight.  Both operands are activations streamed once from HBM, and a
-        // K-tile's LDS-DMA is complete only when its slowest line has arrived: with ONE tile (64 KB per CU) in flight
-        // behind the tile being multiplied the loop runs at (loaded HBM latency) per K-tile -- 3.0 us in the training
-        // step where the matrix pipe needs 1.0 (rocprofv3, serial step: 788 us for 261 K-tiles).  The image of a
-        // K-tile is two independent halves (token rows 0-31 = k-steps 0,1 and rows 32-63 = k-steps 2,3; a wave's DMA
-        // instructions alternate between them), so each half is re-filled as soon as BOTH wave groups have read it:
-        //   tile kt, after barrier #4 of tile kt-1 : H1(kt+1) -> other buffer, rows 32-63 (tile kt-1 is done with them)
-        //   tile kt, after barrier #2              : H0(kt+2) -> this buffer, rows 0-31  (tile kt is done with them)
-        // Every half now has 1.5 tile times to land instead of < 1, and the waits are COUNTED (LDS-DMA completes in
-        // issue order): before the barrier that opens a half for reading a wave leaves exactly the younger halves it
-        // has issued since outstanding (4 DMA instructions per half and wave).
-        static_assert(NW == 8 && IA % 2 == 0 && IB % 2 == 0, "half-tile staging: 8 waves, even instruction counts");
-        auto stage_half = [&](int buf, int kt, int hf) {
-            char* s = smem + buf * STAGE;
-#pragma unroll
-            for (int i = 0; i < IA; ++i)
-                if ((i & 1) == hf) {       // instruction (i * 8 + wave): rows 4 * ((i * 8 + wave) & 15) ..+3 -> half (i & 1)
-                    const int gr = kt * 64 + a_row[i];
-                    const T* src = gr < p.M ? (const T*)p.A + (size_t)gr * p.lda + a_off[i] : (const T*)tn_zero_page;
-                    glds16(src, s + (i * NW + wave) * 1024);
-                }
-#pragma unroll
-            for (int i = 0; i < IB; ++i)
-                if ((i & 1) == hf) {
-                    const int gr = min(kt * 64 + b_row[i], p.M - 1);
-                    glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
-                }
-        };
-        constexpr int PER_HALF = (IA + IB) / 2;
-        auto wait_leaving = [&](int halves) {       // s_waitcnt vmcnt(halves * PER_HALF), halves wave-uniform in 0..2
-            static_assert(PER_HALF == 4, "counted waits are written for 4 DMA instructions per half");
-            if (halves >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (halves == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
+        // One whole K-tile is staged at the start of the first MFMA segment of the previous tile and waited for by the
+        // issuing wave before the barrier that opens it.  Measured against a half-tile variant with 1.5 K-tiles in
+        // flight and counted waits (DMA issued in the read segments): 610 vs 650 us for the two-block launch, 527 vs
+        // 585 us with L2-resident operands -- what bounds this loop is the CU's L1 fill rate, not exposed latency, and
+        // DMA issue beside the partner group's LDS reads costs more than the extra half tile in flight buys.
         stage(0, kt0);
-        if (kt0 + 1 < kt1) stage_half(1, kt0 + 1, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) bar();
         for (int kt = kt0; kt < kt1; ++kt) {
-            const int cb = (kt - kt0) & 1;
-            const char* cur = smem + cb * STAGE;
-            const bool n1 = kt + 1 < kt1, n2 = kt + 2 < kt1;
-            if (n1) stage_half(cb ^ 1, kt + 1, 1);                 // H1(kt+1)
+            const char* cur = smem + ((kt - kt0) & 1) * STAGE;
+            const bool more = kt + 1 < kt1;
             read_step(cur, kt, 0, af[0], bf[0]);
             read_step(cur, kt, 1, af[1], bf[1]);
-            // H1(kt) (read after the barrier two below / one below) is older than H0(kt+1), H1(kt+1)
-            if (wm == 1) wait_leaving(n1 ? 2 : 0);
-            bar();                                                  // #1
+            bar();
+            if (more) stage((kt - kt0 + 1) & 1, kt + 1);
             mfma_half();
-            if (wm == 0) wait_leaving(n1 ? 2 : 0);
-            bar();                                                  // #2: both groups are done with rows 0-31
-            if (n2) stage_half(cb, kt + 2, 0);                      // H0(kt+2)
+            bar();
             read_step(cur, kt, 2, af[0], bf[0]);
             read_step(cur, kt, 3, af[1], bf[1]);
-            // H0(kt+1) (read at the start of the next tile) is older than H1(kt+1), H0(kt+2)
-            if (wm == 1 && n1) wait_leaving(n2 ? 2 : 1);
-            bar();                                                  // #3
+            if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
             mfma_half();
-            if (wm == 0 && n1) wait_leaving(n2 ? 2 : 1);
-            bar();                                                  // #4: both groups are done with rows 32-63
+            if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
         }
         if (wm == 0) bar();
     } else {

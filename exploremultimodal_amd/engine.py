@@ -304,12 +304,10 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, meta, *params):
-        (g1, g2, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b) = params[:11]
         nexp = len(meta.expert_ranges)
         experts = [params[11 + 4 * i: 15 + 4 * i] for i in range(nexp)]
-        pl, d, H, hid = meta.plan, meta.d, meta.heads, meta.hidden
+        pl, d, H = meta.plan, meta.d, meta.heads
         M, dev = x.shape[0], x.device
-        sh = meta.shadows
         need_bwd = any(ctx.needs_input_grad)   # grad mode is off inside forward; this reflects the caller's
         x = x.contiguous()
         launches = pl.attn_launches(meta.fused)
@@ -318,49 +316,9 @@ class BlockFn(torch.autograd.Function):
         sb = torch.empty(16 * M * d, dtype=torch.bfloat16, device=dev)
         sf = torch.empty(M * d + 4 * M + sum(lse_sizes), dtype=torch.float32, device=dev)
         x2 = torch.empty((M, d), dtype=torch.float32, device=dev)
-        qkv_bias = sh.qkv_bias(q_bias, v_bias)
         D = hip.BlockDesc()
-        D.M, D.d, D.hidden, D.heads = M, d, hid, H
-        D.n_experts = nexp
-        for i, (r0, n) in enumerate(meta.expert_ranges):
-            D.exp_row0[i], D.exp_rows[i] = r0, n
-        D.n_attn = len(launches)
-        pb, pf = sb.data_ptr(), sf.data_ptr()
-        md2 = M * d * 2
-        D.y1, D.qkv, D.ctx, D.zd1, D.y2 = pb, pb + md2, pb + 4 * md2, pb + 5 * md2, pb + 6 * md2
-        D.u, D.h, D.zd2 = pb + 7 * md2, pb + 11 * md2, pb + 15 * md2
-        D.x1 = pf
-        st = pf + M * d * 4
-        D.mean1, D.rstd1, D.mean2, D.rstd2 = st, st + 4 * M, st + 8 * M, st + 12 * M
-        off = st + 16 * M
-        for i, ((seg, nseq, ml), sz) in enumerate(zip(launches, lse_sizes)):
-            D.seg[i], D.nseq[i], D.maxlen[i] = seg.data_ptr(), nseq, ml
-            D.lse_stride[i] = ((ml + 31) // 32) * 32
-            D.lse[i] = off
-            off += sz * 4
-        D.keymask = hip._p(pl.keymask)
-        D.eps = meta.eps
-        D.drop_thresh, D.inv_keep = meta.drop
-        D.attn_drop_thresh, D.attn_inv_keep = meta.attn_drop
-        D.seed = meta.seed & 0xFFFFFFFFFFFFFFFF
-        D.rs1, D.rs2 = hip._p(meta.rs1), hip._p(meta.rs2)
-        D.row_index = pl.row_group.data_ptr() if meta.rs1 is not None else None
-        D.tile, D.need_bwd = meta.tile, int(need_bwd)
-        D.g1, D.g2, D.n1w, D.n1b, D.n2w, D.n2b = (t.data_ptr() for t in (g1, g2, n1w, n1b, n2w, n2b))
-        D.qkv_bias, D.proj_b = qkv_bias.data_ptr(), proj_b.data_ptr()
-        keep = [sb, sf, qkv_bias, pl]
-        w, wt = sh.get(qkv_w)
-        D.qkv_w, D.qkv_wT = w.data_ptr(), wt.data_ptr()
-        keep += [w, wt]
-        w, wt = sh.get(proj_w)
-        D.proj_w, D.proj_wT = w.data_ptr(), wt.data_ptr()
-        keep += [w, wt]
-        for i, (w1, b1, w2, b2) in enumerate(experts):
-            a, at = sh.get(w1)
-            c, ct = sh.get(w2)
-            D.w1[i], D.w1T[i], D.w2[i], D.w2T[i] = a.data_ptr(), at.data_ptr(), c.data_ptr(), ct.data_ptr()
-            D.b1[i], D.b2[i] = b1.data_ptr(), b2.data_ptr()
-            keep += [a, at, c, ct]
+        keep = [sb, sf, pl]
+        _fill_forward(D, meta, params, launches, lse_sizes, M, sb.data_ptr(), sf.data_ptr(), need_bwd, keep)
         D.x, D.x2 = x.data_ptr(), x2.data_ptr()
         hip.block_fwd(D)
         if need_bwd:
@@ -397,25 +355,7 @@ class BlockFn(torch.autograd.Function):
             whole = torch.zeros(shared_n + nexp * exp_n, dtype=f32, device=dev)
             flats = [whole[:shared_n]] + [whole[shared_n + i * exp_n: shared_n + (i + 1) * exp_n] for i in range(nexp)]
 
-        def carve(flat, shapes):
-            out, off = [], 0
-            for shp in shapes:
-                n = 1
-                for s_ in shp:
-                    n *= s_
-                out.append(flat[off:off + n].view(*shp))
-                off += n
-            return out
-
-        (dg1, dg2, dn1w, dn1b, dn2w, dn2b, dqkv_w, dproj_w, dproj_b, dqkv_b) = carve(
-            flats[0], [(d,)] * 6 + [(3 * d, d), (d, d), (d,), (3 * d,)])
-        D.dg1, D.dg2, D.dn1w, D.dn1b, D.dn2w, D.dn2b = (t.data_ptr() for t in (dg1, dg2, dn1w, dn1b, dn2w, dn2b))
-        D.dqkv_w, D.dproj_w, D.dproj_b, D.dqkv_b = (t.data_ptr() for t in (dqkv_w, dproj_w, dproj_b, dqkv_b))
-        dexp = []
-        for i in range(nexp):
-            dw1, db1, dw2, db2 = carve(flats[1 + i], [(hid, d), (hid,), (d, hid), (d,)])
-            D.dw1[i], D.db1[i], D.dw2[i], D.db2[i] = dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
-            dexp += [dw1, db1, dw2, db2]
+        grads = _fill_grads(D, flats, d, hid, nexp)
         # temporaries: dz2 | du(4) | dy2(=dctx) | dz1 | dqkv(3) | dy1  bf16 ; dx1, dx0 fp32
         tb = torch.empty(11 * M * d, dtype=torch.bfloat16, device=dev)
         dx1 = torch.empty((M, d), dtype=f32, device=dev)
@@ -442,7 +382,6 @@ class BlockFn(torch.autograd.Function):
         D.ws_tn, D.ws_tn_bytes = ws_tn.data_ptr(), ws_tn.numel() * 4
         hip.block_bwd(D)
         ctx.desc = ctx.keep = None
-        grads = [dg1, dg2, dn1w, dn1b, dqkv_w, dqkv_b[:d], dqkv_b[2 * d:], dproj_w, dproj_b, dn2w, dn2b] + dexp
         if sink is not None:
             # the bucket IS the gradient storage: p.grad become views of it, autograd gets nothing to add
             for p_, g_ in zip(params, grads):
