@@ -787,18 +787,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p
 // VLMo-Base has 9-36 output tiles, so on its own it needs a 7-way split of the token dimension (slabs + a reduction
 // pass, or atomics) to occupy 256 CUs; the gradients of two blocks together have 216 tiles and need no split at all.
 constexpr int MAX_TN_PROBS = 16;
+// Workgroup b of the launch runs order[b] = (problem << 12) | (workgroup index inside the problem), or nothing
+// (TN_NOP).  The host fills the table so that the workgroups one XCD receives (b % 8 equal, dealt round-robin) are
+// a BALANCED mix: with problems of different reduction lengths in one launch (below the fusion layer: 261, 197 and
+// 64 K-tiles) contiguous XCD chunks gave one XCD 45 long tiles for its 32 CUs -- two rounds, 1 035 us instead of
+// 525 -- while another finished its 45 short ones in a quarter of the time.
+constexpr int MAX_TN_ORDER = 1024;
+constexpr uint16_t TN_NOP = 0xFFFF;
 struct GemmTNMulti {
     int n;
-    int t0[MAX_TN_PROBS + 1];
     GemmTN p[MAX_TN_PROBS];
+    uint16_t order[MAX_TN_ORDER];
 };
 template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti mp) {
-    const int lid_all = xcd_remap(blockIdx.x, gridDim.x);
-    int gi = 0;
-#pragma unroll
-    for (int q = 1; q < MAX_TN_PROBS; ++q)
-        if (q < mp.n && lid_all >= mp.t0[q]) gi = q;
+    const uint32_t code = mp.order[blockIdx.x];
+    if (code == TN_NOP) return;
+    int gi = (int)(code >> 12);
+    const int lid_in = __builtin_amdgcn_readfirstlane((int)(code & 0xFFFu));
     gi = __builtin_amdgcn_readfirstlane(gi);
     // copy the chosen problem into SGPRs ONCE: a dynamically indexed kernarg struct is otherwise re-read with
     // s_load + s_waitcnt at every use inside the K loop (908 scalar loads in the first build of this kernel)
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti
     p.alpha = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.alpha)));
     p.slab = nullptr;
     p.mode = __builtin_amdgcn_readfirstlane(q.mode);
-    gemm_tn_body<T, 256, 256, 2, 4, true>(p, lid_all - __builtin_amdgcn_readfirstlane(mp.t0[gi]));
+    gemm_tn_body<T, 256, 256, 2, 4, true>(p, lid_in);
 }
 
 // C[r, c] += alpha * sum_s slab[s, r, c]   (one float4 per thread)
@@ -1164,7 +1170,11 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         if (force_splits > 0) splits = force_splits;
         GemmTNMulti mp{};
         mp.n = nq;
-        int t = 0;
+        struct Job {
+            uint16_t code;
+            int cost;
+        };
+        std::vector<Job> jobs;
         for (int q = 0; q < nq; ++q) {
             const VlmoTnProblem& r = probs[q0 + q];
             const int tiles = ((r.N1 + 255) / 256) * ((r.N2 + 255) / 256);
@@ -1183,11 +1193,32 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
                     }
                 }
             }
+            VLMO_CHECK_ARG(tiles * sp <= 4096, "vlmo_gemm_tn_multi: problem %d has too many tiles", q0 + q);
             mp.p[q] = GemmTN{r.A, r.B, r.C, r.M, r.N1, r.N2, r.lda, r.ldb, r.ldc, per, tiles, r.alpha, nullptr, mode};
-            mp.t0[q] = t;
-            t += tiles * sp;
+            for (int l = 0; l < tiles * sp; ++l) jobs.push_back(Job{(uint16_t)((q << 12) | l), per});
         }
-        for (int q = nq; q <= MAX_TN_PROBS; ++q) mp.t0[q] = t;
+        // placement: classes of equal reduction length, longest first; every class is cut into 8 contiguous runs (a
+        // run = neighbouring tiles of one problem: they share operand panels through the XCD's L2) and XCD x takes run
+        // x of every class, so all XCDs get the same mix and, inside an XCD, long tiles are dispatched before short ones
+        std::stable_sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.cost > b.cost; });
+        std::vector<uint16_t> bins[8];
+        for (size_t i = 0; i < jobs.size();) {
+            size_t j = i;
+            while (j < jobs.size() && jobs[j].cost == jobs[i].cost) ++j;
+            const size_t cnt = j - i;
+            for (int x = 0; x < 8; ++x)
+                for (size_t k = i + cnt * x / 8; k < i + cnt * (x + 1) / 8; ++k) bins[x].push_back(jobs[k].code);
+            i = j;
+        }
+        size_t deepest = 0;
+        for (int x = 0; x < 8; ++x) deepest = bins[x].size() > deepest ? bins[x].size() : deepest;
+        VLMO_CHECK_ARG(deepest * 8 <= (size_t)MAX_TN_ORDER, "vlmo_gemm_tn_multi: %zu workgroups exceed one launch (pass fewer problems per call)",
+                       jobs.size());
+        const int t = (int)deepest * 8;
+        for (int b = 0; b < t; ++b) {
+            const std::vector<uint16_t>& bin = bins[b & 7];
+            mp.order[b] = (size_t)(b >> 3) < bin.size() ? bin[b >> 3] : TN_NOP;
+        }
         ProfScope prof(73, flops, stream);
         constexpr int LDS = 2 * 4 * 64 * 256;
         if (dtype == VLMO_F16)
