@@ -286,7 +286,10 @@ def main():
             fl = 3 * (4 * fl // 3 + 2 * v_only + l_only) + int(52.119e9)      # + dVAE forward per image
         # dominant kernel: per-symbol totals from the event pairs recorded in the timed region
         per = {sym: [sec, flops, n] for sym, (sec, flops, n) in prof.items()}
-        dom = max(per.items(), key=lambda kv: kv[1][0]) if per else None
+        # dominant kernel = the symbol that carries the largest share of the step's algorithmic flops (the batched
+        # weight-gradient launch: 32 %).  Ranking by event time is unstable in the overlapped step: a main-stream launch
+        # that starts beside a weight-gradient launch queues for compute units (dgrad_fc2: 136 us alone, 281 us then)
+        dom = max(per.items(), key=lambda kv: kv[1][1]) if per else None
         roof = None
         if dom:
             sym, (tsec, flops, n) = dom
