@@ -1141,8 +1141,15 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
-    for (int q0 = 0; q0 < n; q0 += MAX_TN_PROBS) {
-        const int nq = n - q0 < MAX_TN_PROBS ? n - q0 : MAX_TN_PROBS;
+    for (int q0 = 0, nq = 0; q0 < n; q0 += nq) {
+        // one launch = as many of the remaining problems as fit the problem table and the placement table
+        nq = 0;
+        for (long tl = 0; q0 + nq < n && nq < MAX_TN_PROBS; ++nq) {
+            const VlmoTnProblem& r = probs[q0 + nq];
+            const long t = (long)((r.N1 + 255) / 256) * ((r.N2 + 255) / 256);
+            if (nq > 0 && tl + t > MAX_TN_ORDER - 64) break;
+            tl += t;
+        }
         long tiles_all = 0;
         int min_nk = 1 << 30;
         double flops = 0;

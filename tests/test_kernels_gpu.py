@@ -522,3 +522,20 @@ def test_colwork_multi():
     assert torch.equal(q, torch.zeros_like(q))
     _close(cs, x[:, :512].float().sum(0), 1e-5, 1e-3, 'colsum')
     _close(cs2, 1 + x2.float().sum(0), 1e-5, 1e-3, 'colsum small')
+
+
+def test_gemm_tn_multi_more_tiles_than_one_placement_table():
+    """20 problems x 64 tiles = 1 280 workgroups: more than one launch's placement table (1 024) holds, so the call
+    is cut into several launches; mixed reduction lengths exercise the cost-balanced XCD placement."""
+    g = torch.Generator().manual_seed(8)
+    probs, refs = [], []
+    for i in range(20):
+        M = 64 * (1 + i % 3) + (5 if i % 4 == 0 else 0)
+        A = torch.randint(-2, 3, (M, 2048), generator=g).float()
+        B = torch.randint(-2, 3, (M, 2048), generator=g).float()
+        probs.append((A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), torch.zeros(2048, 2048, device=DEV), M, 2048, 2048, i % 2 == 0))
+        refs.append(A.t() @ B)
+    hip.gemm_tn_multi(probs)
+    torch.cuda.synchronize()
+    for p, r in zip(probs, refs):
+        assert torch.equal(p[2].cpu(), r)
