@@ -310,6 +310,8 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
     const void *ag[4], *wg[4], *af[4], *wf[4];
     int32_t rows[4];
     VlmoEpilogue eg[4], ef[4];
+    static const bool fold_db1 = !getenv("VLMO_FOLD_DB1") || atoi(getenv("VLMO_FOLD_DB1")) != 0;   // measurement aid
+    int64_t colpart_off = (int64_t)(3 + b->n_experts) * slot / 4;       // floats
     for (int x = 0; x < b->n_experts; ++x) {
         const size_t r0 = b->exp_row0[x];
         const int n = rows[x] = b->exp_rows[x];
@@ -329,6 +331,24 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
+        // fc1 bias gradient: the DGELU epilogue leaves column sums per 64-row block behind the (3 + experts) fold
+        // slots when the workspace has room; they join the block's other column folds.  Else: a pass over du.
+        const int nblk64 = (n + 63) / 64;
+        if (fold_db1 && b->db1[x] && (colpart_off + (int64_t)nblk64 * hid) * 4 <= b->ws_bytes) {
+            e.colpart = (float*)b->ws_main + colpart_off;
+            colpart_off += (int64_t)nblk64 * hid;
+            VlmoColJob j{};
+            j.kind = 0;
+            j.ld = hid;
+            j.src = e.colpart;
+            j.rows = nblk64;
+            j.ncols = hid;
+            j.out[0] = b->db1[x];
+            j.n0 = hid;
+            D.col.push_back(j);
+        } else {
+            push_colsum(D, bp(b->du, r0, hid, 2), hid, n, hid, b->db1[x]);
+        }
         af[x] = bp(b->du, r0, hid, 2);
         wf[x] = b->w1T[x];
         VlmoEpilogue& f = ef[x] = epi();
@@ -336,7 +356,6 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
         f.ldo = d;
         push_tn(D, bp(b->dz2, r0, d, 2), d, bp(b->h, r0, hid, 2), hid, b->dw2[x], hid, n, d, hid);
         push_tn(D, bp(b->du, r0, hid, 2), hid, bp(b->y2, r0, d, 2), d, b->dw1[x], d, n, hid, d);
-        push_colsum(D, bp(b->du, r0, hid, 2), hid, n, hid, b->db1[x]);
     }
     TRY(vlmo_gemm_nt_grouped(VLMO_EPI_DGELU, VLMO_BF16, b->tile, b->n_experts, ag, d, wg, d, rows, hid, d, eg, st));
     TRY(vlmo_gemm_nt_grouped(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->n_experts, af, hid, wf, hid, rows, d, hid, ef, st));
@@ -358,7 +377,10 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
                           b->seed + 11 + a, st));
     push_tn(D, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d);
     push_tn(D, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d);
-    push_colsum(D, b->dqkv, 3 * d, M, 3 * d, b->dqkv_b);
+    // q and v thirds only: the k third of the bias is a constant zero (vlmo.py:71-75), and its gradient vanishes
+    // anyway (the soft-max is invariant to a shift of the scores along the keys)
+    push_colsum(D, b->dqkv, 3 * d, M, d, b->dqkv_b);
+    push_colsum(D, bp(b->dqkv, 0, 0, 2) + 4 * (size_t)d, 3 * d, M, d, b->dqkv_b + 2 * d);
     {
         VlmoEpilogue e = epi();
         e.out = b->dy1;

@@ -79,8 +79,8 @@ template <> __device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
 // row segment and `rs` = drop-path scale: loaded for a whole pass BEFORE any math so the ~1-2 us
 // global latencies overlap instead of serialising load -> math -> store per row group).
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue4(const GemmNT& p, int gmb, int row, int gn, f32x4 v, f32x4 bias4,
-                                          f32x4 gamma4, f32x4 ext, float rs) {
+__device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, int gn, f32x4 v, f32x4 bias4,
+                                           f32x4 gamma4, f32x4 ext, float rs) {
     const VlmoEpilogue& e = p.e;
     v += bias4;
     // wave-uniform 64-bit row base (scalar unit) + 32-bit in-tile offset: a per-lane 64-bit
@@ -144,6 +144,7 @@ __device__ __forceinline__ void epilogue4(const GemmNT& p, int gmb, int row, int
         }
         store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     }
+    return v;
 }
 
 // the row segment an epilogue needs from global memory besides the accumulators (clamped row: always valid)
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
     if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
     if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};      // EPI_DGELU: column sums of a 64-row block (fc1 bias gradient partials)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // issue this pass's global loads first: they fly while the accumulators go through LDS
@@ -501,12 +503,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                     pv[3] = labv;
                 }
             } else {
-                if (gm < p.M && col_ok) epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it]);
+                if (gm < p.M && col_ok) {
+                    const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it]);
+                    if constexpr (EPI == EPI_DGELU) csum += w;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (EPI == EPI_DGELU) {
+            // column sums of du per 64-row block -> colpart[block][N]: the fc1 bias gradient is their fold, done with the
+            // other column folds of the block instead of a second pass over the [M, hidden] matrix
+            static_assert(TM % 2 == 0, "64-row partial blocks");
+            if ((i & 1) && p.e.colpart) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o, 64);
+                const int blk = (gmb - 32) >> 6;
+                if (lane < LPR && col_ok && blk * 64 < p.M) *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
+                csum = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
 }
 

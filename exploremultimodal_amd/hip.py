@@ -27,7 +27,7 @@ class Epilogue(ctypes.Structure):
                 ('resid', _vp), ('row_scale', _vp), ('row_index', _vp), ('aux', _vp),
                 ('ldo', _i32), ('ld2', _i32), ('relu', _i32),
                 ('drop_thresh', _u32), ('inv_keep', _f32), ('beta', _f32),
-                ('seed', _u64)]
+                ('seed', _u64), ('colpart', _vp)]
 
 
 _fp = _vp      # device pointers are passed as integers (tensor.data_ptr())
@@ -121,6 +121,7 @@ _SIGS = {
 }
 
 _lib = None
+ABI_VERSION = 2      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
 
 def lib():
     """Load (once) and return the C-ABI library; raise loudly if it is missing."""
@@ -134,6 +135,9 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vlmo_last_error.restype = ctypes.c_char_p
         L.vlmo_abi_version.restype = ctypes.c_int
+        if L.vlmo_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'{LIB_PATH} has ABI version {L.vlmo_abi_version()}, this package needs {ABI_VERSION}: '
+                               'rebuild it (make -C exploremultimodal_amd/csrc)')
         L.vlmo_reduce_ws_bytes.restype = ctypes.c_int64
         L.vlmo_reduce_ws_bytes.argtypes = [_i32]
         L.vlmo_gemm_tn_ws_bytes.restype = ctypes.c_int64
@@ -194,12 +198,12 @@ def drop_params(p, training):
 
 def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=None,
             row_scale=None, row_index=None, aux=None, ldo=None, ld2=None, relu=False, drop=(0, 1.0), seed=0,
-            beta=0.0, tile=-1, lda=None, ldb=None):
+            beta=0.0, tile=-1, lda=None, ldb=None, colpart=None):
     e = Epilogue(_p(out), _p(out2), _p(bias), _p(gamma), _p(resid), _p(row_scale), _p(row_index), _p(aux),
                  ldo if ldo is not None else out.stride(0),
                  ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else
                                               (aux.stride(0) if aux is not None else 0)),
-                 int(relu), drop[0], drop[1], beta, seed & 0xFFFFFFFFFFFFFFFF)
+                 int(relu), drop[0], drop[1], beta, seed & 0xFFFFFFFFFFFFFFFF, _p(colpart))
     rc = lib().vlmo_gemm_nt(epi, _dt(A), tile, _p(A), lda if lda is not None else A.stride(0),
                             _p(B), ldb if ldb is not None else B.stride(0), M, N, K,
                             ctypes.byref(e), _stream())
@@ -220,7 +224,7 @@ def gemm_nt_grouped(epi, As, Bs, Ms, N, K, outs, *, per_group=None, tile=-1, **c
                          _p(kw.get('row_scale')), _p(kw.get('row_index')), _p(aux), out.stride(0),
                          out2.stride(0) if out2 is not None else (aux.stride(0) if aux is not None else 0),
                          int(kw.get('relu', False)), drop[0], drop[1], kw.get('beta', 0.0),
-                         kw.get('seed', 0) & 0xFFFFFFFFFFFFFFFF)
+                         kw.get('seed', 0) & 0xFFFFFFFFFFFFFFFF, _p(kw.get('colpart')))
     pa = (ctypes.c_void_p * n)(*[_p(a) for a in As])
     pb = (ctypes.c_void_p * n)(*[_p(b) for b in Bs])
     ms = (ctypes.c_int32 * n)(*Ms)

@@ -69,6 +69,9 @@ typedef struct VlmoEpilogue {
     float inv_keep;         /* 1 / (1 - p)                                  */
     float beta;
     uint64_t seed;
+    float* colpart;         /* VLMO_EPI_DGELU: [ceil(M/64), N] fp32 or NULL: row b = column sums of  */
+                            /* the values written to out rows [64b, 64b+64) -- the fc1 bias gradient */
+                            /* is the fold of these rows (vlmo_colwork_multi kind 0); plain stores   */
 } VlmoEpilogue;
 
 const char* vlmo_last_error(void);

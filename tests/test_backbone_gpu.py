@@ -244,7 +244,9 @@ def test_native_stack_path_equals_per_block_path(preset, B):
     vlmo_gemm_tn_multi launches) against engine.BlockFn (one call per block), training mode with dropout and
     drop-path from the same seed: the forward output is bit-identical (same kernels, same order); the activation-
     gradient chain is the same too, so what differs is only the summation order inside the weight gradients and
-    column sums (fp32: 1e-4 of the gradient's largest element)."""
+    column sums (fp32: 1e-4 of the gradient's largest element) -- except the fc1 bias gradient, which the stack path
+    folds from the fp32 values in the GELU-derivative epilogue while the per-block path sums the bf16-rounded du
+    matrix afterwards (bf16 rounding of every addend: 4e-3)."""
     from exploremultimodal_amd import engine
     model, mc = build(preset, drop=0.1, drop_path=0.1)
     model.train()
@@ -262,7 +264,7 @@ def test_native_stack_path_equals_per_block_path(preset, B):
     assert torch.equal(xs, xb), (xs - xb).abs().max()
     assert set(gs) == set(gb)
     for n in gb:
-        tol = 1e-4 * gb[n].abs().max().item() + 1e-9
+        tol = (4e-3 if n.endswith('fc1.bias') else 1e-4) * gb[n].abs().max().item() + 1e-9
         assert (gs[n] - gb[n]).abs().max().item() <= tol, (n, (gs[n] - gb[n]).abs().max().item(), tol)
 
 
