@@ -288,8 +288,13 @@ void push_tn(Deferred& D, const void* A, int lda, const void* B, int ldb, float*
     D.tn.push_back(VlmoTnProblem{A, B, C, lda, ldb, ldc, M, N1, N2, 1.f, 1});
 }
 
-// activation-gradient chain of one block on `st`; parameter-gradient work is appended to D
-int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
+// activation-gradient chain of one block on `st`; parameter-gradient work is appended to D.
+// `below` = the block processed next (the one under this one in the stack), or NULL: when its FFN residual branch can
+// take its incoming gradient straight from this block's last kernel, norm1's backward and that branch's backward run as
+// ONE kernel (the 51 MB fp32 gradient is not re-read) and *fused_below is set; the chain of `below` is then started
+// with skip_resid.
+int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D, const VlmoBlockDesc* below, bool skip_resid,
+                      bool* fused_below) {
     const int M = b->M, d = b->d, hid = b->hidden;
     const int64_t slot = reduce_ws_need(2 * d);
     VLMO_CHECK_ARG(b->dx2 && b->dx1 && b->dx0, "vlmo_stack_bwd: null gradient buffers");
@@ -311,16 +316,18 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
     int32_t rows[4];
     VlmoEpilogue eg[4], ef[4];
     static const bool fold_db1 = !getenv("VLMO_FOLD_DB1") || atoi(getenv("VLMO_FOLD_DB1")) != 0;   // measurement aid
-    int64_t colpart_off = (int64_t)(3 + b->n_experts) * slot / 4;       // floats
+    int64_t colpart_off = (int64_t)(4 + b->n_experts) * slot / 4;       // floats (behind the fold slots)
     for (int x = 0; x < b->n_experts; ++x) {
         const size_t r0 = b->exp_row0[x];
         const int n = rows[x] = b->exp_rows[x];
-        arm();
-        TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2,
-                           b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr),
-                           b->row_index ? b->row_index + r0 : nullptr, bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d,
-                           b->drop_thresh, b->inv_keep, b->seed + 21 + 2 * x, ws_slot(2 + x), slot, st));
-        collect();
+        if (!skip_resid) {
+            arm();
+            TRY(vlmo_resid_bwd(b->dx2 + r0 * d, bp(b->zd2, r0, d, 2), b->g2,
+                               b->row_index ? b->rs2 : (b->rs2 ? b->rs2 + r0 : nullptr),
+                               b->row_index ? b->row_index + r0 : nullptr, bp(b->dz2, r0, d, 2), b->dg2, b->db2[x], n, d,
+                               b->drop_thresh, b->inv_keep, b->seed + 21 + 2 * x, ws_slot(2 + x), slot, st));
+            collect();
+        }
         ag[x] = bp(b->dz2, r0, d, 2);
         wg[x] = b->w2T[x];
         VlmoEpilogue& e = eg[x] = epi();
@@ -387,6 +394,37 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D) {
         e.ldo = d;
         TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dqkv, 3 * d, b->qkv_wT, 3 * d, M, d, 3 * d, &e, st));
     }
+    static const bool fuse_below = !getenv("VLMO_FUSE_BELOW") || atoi(getenv("VLMO_FUSE_BELOW")) != 0;   // measurement aid
+    const VlmoBlockDesc* n = fuse_below ? below : nullptr;
+    *fused_below = false;
+    if (n && n->M == M && n->d == d && n->dx2 == b->dx0 && n->zd2 && n->dz2 && n->n_experts >= 1 && n->n_experts <= 2 &&
+        n->exp_row0[0] == 0 && (n->n_experts == 1 ? n->exp_rows[0] == M
+                                                   : (n->exp_row0[1] == n->exp_rows[0] && n->exp_rows[0] + n->exp_rows[1] == M)) &&
+        b->ws_bytes >= (int64_t)(4 + b->n_experts) * slot) {
+        const int seg = n->n_experts == 1 ? M : n->exp_row0[1];
+        float* wsf = ws_slot(2 + b->n_experts);        // [workgroups][4d]: two slots
+        int nb0 = 0, nblk = 0;
+        arm();
+        TRY(ln_resid_seg_bwd(b->dy1, b->x, b->n1w, b->mean1, b->rstd1, b->dx1, b->dx0, b->dn1w, b->dn1b, n->zd2, n->g2,
+                             n->rs2, n->row_index, n->dz2, n->dg2, n->drop_thresh, n->inv_keep, n->seed + 21, n->seed + 23,
+                             seg, M, d, wsf, 2 * slot, &nb0, &nblk, st));
+        collect();
+        // the FFN bias gradients of the block below: columns [3d, 4d) of the partial rows of each segment
+        for (int x = 0; x < n->n_experts; ++x) {
+            if (!n->db2[x]) continue;
+            VlmoColJob j{};
+            j.kind = 0;
+            j.ld = 4 * d;
+            j.src = wsf + 3 * d + (x ? (size_t)nb0 * 4 * d : 0);
+            j.rows = x ? nblk - nb0 : nb0;
+            j.ncols = d;
+            j.out[0] = n->db2[x];
+            j.n0 = d;
+            if (j.rows > 0) D.col.push_back(j);
+        }
+        *fused_below = true;
+        return 0;
+    }
     arm();
     TRY(vlmo_ln_bwd(b->dy1, 0, nullptr, b->x, b->n1w, b->mean1, b->rstd1, b->dx1, b->dx0, b->dn1w, b->dn1b, M, d,
                     ws_slot(2 + b->n_experts), slot, st));
@@ -437,21 +475,29 @@ extern "C" int vlmo_stack_bwd(const VlmoStackDesc* s, hipStream_t st) {
         D.blocks.clear();
         return 0;
     };
+    auto set_free = [&](int kk) -> int {
+        // block kk (processing order) reuses the temporaries of the block processed nsets steps earlier: that block's
+        // deferred work must be done
+        if (!two || kk < nsets || kk >= nb) return 0;
+        int need = batch_of[kk - nsets];
+        if (need < 0 || need >= n_batches) {
+            TRY(flush());
+            need = n_batches - 1;
+        }
+        if (need >= 0 && need > waited_upto) {
+            (void)hipStreamWaitEvent(st, ev.get(2 * need + 1), 0);
+            waited_upto = need;
+        }
+        return 0;
+    };
+    bool skip_resid = false;
     for (int k = 0; k < nb; ++k) {
         const int i = nb - 1 - k;
-        if (two && k >= nsets) {
-            // this block reuses the temporaries of the block processed nsets steps ago: its deferred work must be done
-            int need = batch_of[k - nsets];
-            if (need < 0 || need >= n_batches) {
-                TRY(flush());
-                need = n_batches - 1;
-            }
-            if (need > waited_upto) {
-                (void)hipStreamWaitEvent(st, ev.get(2 * need + 1), 0);
-                waited_upto = need;
-            }
-        }
-        TRY(block_dgrad_chain(&s->blocks[i], st, D));
+        TRY(set_free(k));
+        TRY(set_free(k + 1));       // the last kernel of this chain may already write dz2 of the block below
+        bool fused = false;
+        TRY(block_dgrad_chain(&s->blocks[i], st, D, i > 0 ? &s->blocks[i - 1] : nullptr, skip_resid, &fused));
+        skip_resid = fused;
         D.blocks.push_back(i);
         batch_of[k] = n_batches;
         if ((int)D.blocks.size() >= batch || k == nb - 1) TRY(flush());

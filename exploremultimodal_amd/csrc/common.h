@@ -62,6 +62,12 @@ extern thread_local PartialReduce* vlmo_defer_reduce;
 inline int reduce_partials(const PartialReduce& r, hipStream_t stream) {
     return r.ws ? reduce_partials(r.ws, r.nblk, r.ncols, r.out0, r.n0, r.out1, stream, r.out2, r.out3) : 0;
 }
+// layernorm.hip: LayerNorm backward fused with the residual-branch backward of the block below (see there)
+int ln_resid_seg_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                     const float* dres, float* dx, float* dw, float* db, const void* zd, const float* gamma,
+                     const float* row_scale, const int32_t* row_index, void* dz, float* dgamma, uint32_t drop_thresh,
+                     float inv_keep, uint64_t seed0, uint64_t seed1, int seg, int M, int d, float* ws, int64_t ws_bytes,
+                     int* nb0, int* nblk, hipStream_t stream);
 inline int64_t reduce_ws_need(int ncols) { return (int64_t)VLMO_MAX_PARTIAL_BLOCKS * ncols * 4; }
 
 // ---- element traits: the transformer runs bf16, the dVAE runs fp16 --------

@@ -74,6 +74,12 @@ struct ResidArgs {
     uint32_t thresh;
     float inv_keep;
     uint64_t seed;
+    // rows [seg, M) form a second segment with its own dropout stream (seed1) whose counters restart at row seg:
+    // the per-modality experts of a block below the fusion layer (their FFN residual branches were produced by
+    // separate problems of a grouped GEMM).  seg = M: one segment.  No workgroup straddles the boundary, so the
+    // column partials of the two segments are separate rows of the workspace.
+    int seg;
+    uint64_t seed1;
 };
 
 template <int VPL, bool DY_F32, bool RESID>
@@ -97,8 +103,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         gg[j] = f32x4{1.f, 1.f, 1.f, 1.f};
         if (RESID && ra.gamma && i < nv) gg[j] = ((const f32x4*)ra.gamma)[i];
     }
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(M, r0 + rows_per_block);
+    int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    uint64_t drop_seed = 0;
+    int drop_row0 = 0;
+    if constexpr (RESID) {
+        const int nb0 = (ra.seg + rows_per_block - 1) / rows_per_block;
+        drop_seed = ra.seed;
+        if ((int)blockIdx.x < nb0) {
+            r1 = min(ra.seg, r0 + rows_per_block);
+        } else {
+            r0 = ra.seg + ((int)blockIdx.x - nb0) * rows_per_block;
+            r1 = min(M, r0 + rows_per_block);
+            drop_seed = ra.seed1;
+            drop_row0 = ra.seg;
+        }
+    }
     // Everything a row needs from HBM (dy, x, the incoming residual gradient, mean/rstd) is fetched one row
     // AHEAD of the arithmetic: beside the weight-gradient GEMMs of the side stream this kernel gets one or two
     // waves per SIMD, so its speed is (bytes in flight per wave) / latency, not occupancy.
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                     const f32x4 orr = o * cur.scale;
                     f32x4 v = o * gg[j] * cur.scale;      // same association as resid_bwd_kernel: (dx * gamma) * rs
                     if (ra.thresh) {
-                        const uint64_t bits = drop_bits4(ra.seed, ((uint64_t)m * d + 4 * i) >> 2);
+                        const uint64_t bits = drop_bits4(drop_seed, ((uint64_t)(m - drop_row0) * d + 4 * i) >> 2);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = drop_keep(bits, k, ra.thresh) ? v[k] * ra.inv_keep : 0.f;
                     }
@@ -248,7 +267,13 @@ int ln_bwd_launch(const void* dy, int dy_f32, const int32_t* rowmap, const float
     int rpb = (M + VLMO_MAX_PARTIAL_BLOCKS - 1) / VLMO_MAX_PARTIAL_BLOCKS;
     rpb = ((rpb + 3) / 4) * 4;
     if (rpb < 8) rpb = 8;
-    const int grid = (M + rpb - 1) / rpb;
+    int grid = (M + rpb - 1) / rpb;
+    if (ra && ra->seg < M) {        // two segments: workgroups do not straddle the boundary
+        for (;; rpb += 4) {
+            grid = (ra->seg + rpb - 1) / rpb + (M - ra->seg + rpb - 1) / rpb;
+            if (grid <= VLMO_MAX_PARTIAL_BLOCKS) break;
+        }
+    }
     const ResidArgs none{};
 #define LNB(V)                                                                                         \
     if (ra)                                                                                            \
@@ -283,6 +308,32 @@ extern "C" int vlmo_ln_resid_bwd(const void* dy, const float* x, const float* w,
                                  uint32_t drop_thresh, float inv_keep, uint64_t seed, int M, int d, float* ws,
                                  int64_t ws_bytes, hipStream_t stream) {
     VLMO_CHECK_ARG(zd && dz, "vlmo_ln_resid_bwd: null pointer");
-    const ResidArgs ra{(const bf16*)zd, gamma, row_scale, row_index, (bf16*)dz, drop_thresh, inv_keep, seed};
+    const ResidArgs ra{(const bf16*)zd, gamma, row_scale, row_index, (bf16*)dz, drop_thresh, inv_keep, seed, M, 0};
     return ln_bwd_launch(dy, 0, nullptr, x, w, mean, rstd, dres, dx, dw, db, M, d, ws, ws_bytes, &ra, dgamma, dbias, stream);
+}
+
+// LayerNorm backward of one block fused with the residual-branch backward of the block BELOW it (block.hip: norm1
+// of block i + the FFN branch of block i-1, whose incoming gradient is exactly the dx this kernel writes).  The
+// branch may consist of two row segments [0, seg) and [seg, M) with their own dropout streams (per-modality experts);
+// the caller folds the bias-gradient partials of the segments itself: workspace rows [0, *nb0) belong to segment 0,
+// [*nb0, *nblk) to segment 1, columns [3d, 4d).
+int ln_resid_seg_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                     const float* dres, float* dx, float* dw, float* db, const void* zd, const float* gamma,
+                     const float* row_scale, const int32_t* row_index, void* dz, float* dgamma, uint32_t drop_thresh,
+                     float inv_keep, uint64_t seed0, uint64_t seed1, int seg, int M, int d, float* ws, int64_t ws_bytes,
+                     int* nb0, int* nblk, hipStream_t stream) {
+    VLMO_CHECK_ARG(zd && dz && seg >= 1 && seg <= M, "ln_resid_seg_bwd: bad arguments");
+    const ResidArgs ra{(const bf16*)zd, gamma, row_scale, row_index, (bf16*)dz, drop_thresh, inv_keep, seed0, seg, seed1};
+    int rpb = (M + VLMO_MAX_PARTIAL_BLOCKS - 1) / VLMO_MAX_PARTIAL_BLOCKS;
+    rpb = ((rpb + 3) / 4) * 4;
+    if (rpb < 8) rpb = 8;
+    int grid = (M + rpb - 1) / rpb;
+    if (seg < M)
+        for (;; rpb += 4) {
+            grid = (seg + rpb - 1) / rpb + (M - seg + rpb - 1) / rpb;
+            if (grid <= VLMO_MAX_PARTIAL_BLOCKS) break;
+        }
+    *nb0 = (seg + rpb - 1) / rpb;
+    *nblk = grid;
+    return ln_bwd_launch(dy, 0, nullptr, x, w, mean, rstd, dres, dx, dw, db, M, d, ws, ws_bytes, &ra, dgamma, nullptr, stream);
 }
