@@ -3,6 +3,7 @@
 `no_weight_decay` contracts.  Pretraining losses [mlm, mim, itc, itm]; the downstream
 (vqa / nlvr2 / irtr / mpp), EMA and negative-queue branches raise NotImplementedError
 (out of scope, off in conf/train/pretrain_mum.yaml)."""
+import math
 from collections import defaultdict
 from functools import partial
 
@@ -92,26 +93,26 @@ class VlmoModule(nn.Module):
 
     # ------------------------------------------------------------- checkpoints
     def interpolate_pos_embedding(self, state_dict):
-        """vlmo_module.py:187-232."""
-        for pos_embed_key in ['pos_embed', 'transformer.pos_embed']:
-            if pos_embed_key in state_dict:
-                pos_embed_ckpt = state_dict[pos_embed_key]
-                embedding_size = pos_embed_ckpt.shape[-1]
-                num_patches = self.transformer.patch_embed.num_patches
-                num_extra_tokens = self.transformer.pos_embed.shape[-2] - num_patches
-                orig_size = int((pos_embed_ckpt.shape[-2] - num_extra_tokens) ** 0.5)
-                new_size = int(num_patches ** 0.5)
-                if orig_size != new_size:
-                    extra_tokens = pos_embed_ckpt[:, :num_extra_tokens]
-                    pos_tokens = pos_embed_ckpt[:, num_extra_tokens:]
-                    pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
-                    pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size),
-                                                                 mode='bicubic', align_corners=False)
-                    pos_tokens = pos_tokens.permute(0, 2, 3, 1).flatten(1, 2)
-                    state_dict[pos_embed_key] = torch.cat((extra_tokens, pos_tokens), dim=1)
-        k = 'transformer.txt_embeddings.position_embeddings.weight'
-        if k in state_dict:
-            state_dict[k] = state_dict[k][:self.transformer.max_text_len, :]
+        """Fit a checkpoint's position tables to this model (behaviour of vlmo_module.py:187-232): the image table is
+        resampled bicubically when the checkpoint was trained on another patch grid (class / extra tokens kept as they
+        are), the text table is cut to ``max_text_len`` rows."""
+        tr = self.transformer
+        grid = math.isqrt(tr.patch_embed.num_patches)
+        n_extra = tr.pos_embed.shape[-2] - tr.patch_embed.num_patches
+        for key in ('pos_embed', 'transformer.pos_embed'):
+            table = state_dict.get(key)
+            if table is None:
+                continue
+            src = math.isqrt(table.shape[-2] - n_extra)
+            if src == grid:
+                continue
+            head, body = table[:, :n_extra], table[:, n_extra:]
+            body = body.unflatten(1, (src, src)).movedim(-1, 1)                       # [1, C, src, src]
+            body = torch.nn.functional.interpolate(body, size=(grid, grid), mode='bicubic', align_corners=False)
+            state_dict[key] = torch.cat([head, body.movedim(1, -1).flatten(1, 2)], dim=1)
+        txt = 'transformer.txt_embeddings.position_embeddings.weight'
+        if txt in state_dict:
+            state_dict[txt] = state_dict[txt][:tr.max_text_len]
         state_dict.pop('transformer.txt_embeddings.position_ids', None)   # non-persistent buffer upstream
         return state_dict
 
