@@ -97,6 +97,7 @@ class EncoderBlock(nn.Module):
 
 class Encoder(nn.Module):
     """dall_e/encoder.py:49-133."""
+    group_count = 4     # a class constant upstream (encoder.py:51): instances unpickled from encoder.pkl do not carry it
 
     def __init__(self, group_count=4, n_hid=256, n_blk_per_group=2, input_channels=3, vocab_size=8192,
                  device=torch.device('cpu'), requires_grad=False, use_mixed_precision=True):
@@ -227,10 +228,16 @@ def load_model(path, device=None):
     sys.modules.update(fake)
     try:
         with open(path, 'rb') as f:
-            return torch.load(f, map_location=device, weights_only=False)
+            enc = torch.load(f, map_location=device, weights_only=False)
     finally:
         for name in fake:
             sys.modules.pop(name, None)
+    # unpickling restores the reference objects' __dict__ without running this module's constructors: add the
+    # engine-side state they do not carry
+    for m in enc.modules():
+        if isinstance(m, Conv2d) and '_shadow' not in m.__dict__:
+            m._shadow = None
+    return enc
 
 
 class Dalle_VAE(nn.Module):

@@ -205,6 +205,22 @@ def run_dvae_case(name, B, res, seed=0, full_logits=True, **enc_kw):
     print(f'wrote {name}.npz')
 
 
+def run_dvae_pickle_case(name, **enc_kw):
+    """The wire format of the OpenAI dVAE weights (dall_e/__init__.py:12-21: ``torch.load`` of a pickled
+    ``dall_e.encoder.Encoder`` MODULE, not a state dict): the reference's own Encoder, pickled by torch.save exactly
+    as the published encoder.pkl was, with every parameter's storage emptied so that the fixture carries the object
+    graph (class paths, attribute names and values, module tree) and no megabytes of weights.  The test fills the
+    parameters from oracle/synth.py's key-addressed synthetic state dict."""
+    from dall_e.encoder import Encoder
+    enc = Encoder(**enc_kw).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.set_(torch.empty(0))
+    path = os.path.join(OUT, f'{name}.pkl')
+    torch.save(enc, path)
+    print(f'wrote {name}.pkl ({os.path.getsize(path)} bytes)')
+
+
 def run_module_case(name, preset, B, seed=0, compact_logits=False):
     """Full VlmoModule.forward(batch) with [mlm, mim, itc, itm] (vlmo_module.py:395-436).
     Two call-argument level accommodations, arithmetic untouched:
@@ -294,6 +310,8 @@ def main():
         'dvae_tiny': lambda: run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512),
         'dvae_small': lambda: run_dvae_case('dvae_small', B=2, res=32, n_hid=256, vocab_size=1024),
         'dvae_full_b2': lambda: run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False),
+        'dvae_encoder_pickle': lambda: run_dvae_pickle_case('dvae_encoder_pickle', n_hid=64, vocab_size=512,
+                                                            n_blk_per_group=2),
     }
     want = sys.argv[1:] or list(cases)
     for name in want:
