@@ -28,7 +28,7 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e-3
 
 
-shapes = [('qkv', hip.EPI_BIAS, 2304, 768), ('proj', hip.EPI_RESID, 768, 768), ('fc1', hip.EPI_BIAS_GELU, 3072, 768),
+shapes = [('fc1_bias', hip.EPI_BIAS, 3072, 768), ('qkv', hip.EPI_BIAS, 2304, 768), ('proj', hip.EPI_RESID, 768, 768), ('fc1', hip.EPI_BIAS_GELU, 3072, 768),
           ('fc2', hip.EPI_RESID, 768, 3072), ('dgrad_fc2', hip.EPI_DGELU, 3072, 768), ('dgrad_fc1', hip.EPI_BIAS, 768, 3072),
           ('dgrad_qkv', hip.EPI_BIAS, 768, 2304), ('dgrad_proj', hip.EPI_BIAS, 768, 768)]
 for name, epi, N, K in shapes:
