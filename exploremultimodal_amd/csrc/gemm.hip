@@ -84,9 +84,19 @@ template <> __device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
 // from global memory is passed in (bias/gamma: loaded once per tile; `ext` = residual / pre-activation
 // row segment and `rs` = drop-path scale: loaded for a whole pass BEFORE any math so the ~1-2 us
 // global latencies overlap instead of serialising load -> math -> store per row group).
+// keeps the four values live in registers HERE: hipcc otherwise sinks the arithmetic that produced them into the
+// guarded block of their only user (the store) -- see epilogue4
+__device__ __forceinline__ void pin4(f32x4& v) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
 template <typename T, int EPI>
 __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, int gn, f32x4 v, f32x4 bias4,
-                                           f32x4 gamma4, f32x4 ext, float rs) {
+                                           f32x4 gamma4, f32x4 ext, float rs, bool ok) {
+    // ALL arithmetic runs unconditionally (rows past M compute on clamped inputs) and only the stores sit under
+    // `ok`: with the math inside the guard every guarded block was the first user of a pending load (bias, residual
+    // row) on SOME path, so hipcc put `s_waitcnt vmcnt(0)` in front of each of them -- which also waits for the
+    // previous block's STORE: 32 serialised HBM round trips per wave, ~10 us of a 256x256 tile's epilogue.
     const VlmoEpilogue& e = p.e;
     v += bias4;
     // wave-uniform 64-bit row base (scalar unit) + 32-bit in-tile offset: a per-lane 64-bit
@@ -96,16 +106,16 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, in
     const RowAddr o{(size_t)gmb * e.ldo, (uint32_t)(row * e.ldo + gn)};
     const RowAddr o2{(size_t)gmb * e.ld2, (uint32_t)(row * e.ld2 + gn)};
     if constexpr (EPI == EPI_BIAS) {
-        if (e.relu) {
+        const float lo = e.relu ? 0.f : -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+        pin4(v);
+        if (ok) store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_F32) {
         if (e.beta != 0.f) v += e.beta * ext;
-        *(f32x4*)o.at<float>(e.out) = v;
+        pin4(v);
+        if (ok) *(f32x4*)o.at<float>(e.out) = v;
     } else if constexpr (EPI == EPI_BIAS_GELU) {
-        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);   // u (pre-activation)
         f32x4 h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = gelu_erf(v[j]);
@@ -114,32 +124,47 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) h[j] = drop_keep(bits, j, e.drop_thresh) ? h[j] * e.inv_keep : 0.f;
         }
-        store4<T>(o2.at<T>(e.out2), h[0], h[1], h[2], h[3]);
+        pin4(v);
+        pin4(h);
+        if (ok) {
+            store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);   // u (pre-activation)
+            store4<T>(o2.at<T>(e.out2), h[0], h[1], h[2], h[3]);
+        }
     } else if constexpr (EPI == EPI_RESID) {
         if (e.drop_thresh) {
             const uint64_t bits = drop_bits4(e.seed, ((uint64_t)gm * p.N + gn) >> 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
         }
-        if (e.out2) store4<T>(o2.at<T>(e.out2), v[0], v[1], v[2], v[3]);
-        *(f32x4*)o.at<float>(e.out) = ext + gamma4 * v * rs;
+        f32x4 x2 = ext + gamma4 * v * rs;
+        pin4(v);
+        pin4(x2);
+        if (ok) {
+            if (e.out2) store4<T>(o2.at<T>(e.out2), v[0], v[1], v[2], v[3]);
+            *(f32x4*)o.at<float>(e.out) = x2;
+        }
     } else if constexpr (EPI == EPI_DUAL) {
         // dVAE EncoderBlock tail (dall_e/encoder.py:45-46): out = id + post_gain * res ; out2 = relu(out)
         v = v * e.beta + ext;
-        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
-        if (e.out2)
-            store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f),
-                      fmaxf(v[3], 0.f));
+        pin4(v);
+        if (ok) {
+            store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
+            if (e.out2)
+                store4<T>((T*)e.out2 + (size_t)gm * e.ld2 + gn, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f),
+                          fmaxf(v[3], 0.f));
+        }
     } else if constexpr (EPI == EPI_CE_BWD) {
         // d(cross-entropy)/d(logits) of row gm, recomputed from the logits instead of read back: (softmax - onehot) *
         // row scale (heads.py:86-112 + objectives.py:57-68,571-582).  resid = lse [M], row_scale = dloss / n_valid per
         // row (0 on ignored rows), row_index = labels [M]
-        const float lse = e.resid[gm], sc = e.row_scale[gm];
-        const int lab = e.row_index[gm];
+        const int gmc = min(gm, p.M - 1);
+        const float lse = e.resid[gmc], sc = e.row_scale[gmc];
+        const int lab = e.row_index[gmc];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             v[j] = (__builtin_amdgcn_exp2f((v[j] - lse) * 1.4426950408889634f) - (gn + j == lab ? 1.f : 0.f)) * sc;
-        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
+        pin4(v);
+        if (ok) store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(ext[j]);
@@ -148,7 +173,8 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = drop_keep(bits, j, e.drop_thresh) ? v[j] * e.inv_keep : 0.f;
         }
-        store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
+        pin4(v);
+        if (ok) store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     }
     return v;
 }
@@ -173,10 +199,13 @@ __device__ __forceinline__ f32x4 epilogue_ext(const GemmNT& p, int gmb, int rowc
     }
 }
 
+// The rebuilt pointer is typed GLOBAL before it decays to a generic one: an integer -> generic pointer would make every
+// access through it a FLAT instruction (which counts on vmcnt AND lgkmcnt, so each epilogue store was followed by
+// `s_waitcnt vmcnt(0) lgkmcnt(0)` before the next LDS access: ~10 us of serialised store round trips per 256x256 tile).
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     const uint64_t v = (uint64_t)p;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const void*)(((uint64_t)hi << 32) | lo);
+    return (const void*)(const __attribute__((address_space(1))) void*)(((uint64_t)hi << 32) | lo);
 }
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -215,85 +244,98 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int lid_all = xcd_remap(blockIdx.x, gridDim.x);
-    int gi = 0;
+    // (group, row origin, column origin) of a logical tile
+    auto locate = [&](int la, int& gi_, int& m0_, int& n0_) {
+        int g = 0;
 #pragma unroll
-    for (int q = 1; q < MAX_GROUPS; ++q)
-        if (q < gp.ngroups && lid_all >= gp.t0[q]) gi = q;
-    gi = __builtin_amdgcn_readfirstlane(gi);
-    // (measured A/B in one session: the hoist is neutral-to-better for every epilogue except the GELU-derivative one,
-    // whose register allocation it hurts: dgrad_fc2 126 -> 135 us; that kernel keeps the kernarg reference)
-    const GemmNT& gq = gp.g[gi];
-    GemmNT pl;
-    const GemmNT* pp = &gq;
-    if constexpr (EPI != EPI_DGELU) {
-    // the chosen problem, copied into SGPRs ONCE (see uniform_i): a dynamically indexed kernarg struct is
-    // otherwise re-read with s_load + s_waitcnt at every use (115 scalar loads in the fc1 epilogue before this)
-        pl.A = uniform_ptr(gq.A), pl.B = uniform_ptr(gq.B), pl.zero = uniform_ptr(gq.zero);
-        pl.M = uniform_i(gq.M), pl.N = uniform_i(gq.N), pl.K = uniform_i(gq.K), pl.lda = uniform_i(gq.lda), pl.ldb = uniform_i(gq.ldb);
-        pl.cH = uniform_i(gq.cH), pl.cW = uniform_i(gq.cW), pl.cCin = uniform_i(gq.cCin), pl.ckw = uniform_i(gq.ckw);
-        pl.group_m = uniform_i(gq.group_m);
-        pl.e.out = (void*)uniform_ptr(gq.e.out), pl.e.out2 = (void*)uniform_ptr(gq.e.out2);
-        pl.e.bias = (const float*)uniform_ptr(gq.e.bias), pl.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
-        pl.e.resid = (const float*)uniform_ptr(gq.e.resid), pl.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
-        pl.e.row_index = (const int32_t*)uniform_ptr(gq.e.row_index), pl.e.aux = uniform_ptr(gq.e.aux);
-        pl.e.ldo = uniform_i(gq.e.ldo), pl.e.ld2 = uniform_i(gq.e.ld2), pl.e.relu = uniform_i(gq.e.relu);
-        pl.e.drop_thresh = (uint32_t)uniform_i((int)gq.e.drop_thresh);
-        pl.e.inv_keep = uniform_f(gq.e.inv_keep), pl.e.beta = uniform_f(gq.e.beta);
-        pl.e.seed = (uint64_t)uniform_ptr((const void*)gq.e.seed);
-        pp = &pl;
-    }
-    const GemmNT& p = *pp;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int lid = lid_all - uniform_i(gp.t0[gi]);
-    // grouped order: the ~64 tiles an XCD works on at once form a compact group_m x (64/group_m)
-    // block, so their A row-panels AND B column-panels together fit the XCD's 4 MiB L2
-    const int gm_ = p.group_m > 0 ? p.group_m : 1;
-    const int per_group = gm_ * tiles_n;
-    const int first_m = (lid / per_group) * gm_;
-    const int gsz = min(tiles_m - first_m, gm_);
-    const int in_g = lid % per_group;
-    const int m0 = (first_m + in_g % gsz) * BM, n0 = (in_g / gsz) * BN;
-
+        for (int q = 1; q < MAX_GROUPS; ++q)
+            if (q < gp.ngroups && la >= gp.t0[q]) g = q;
+        g = __builtin_amdgcn_readfirstlane(g);
+        const GemmNT& r = gp.g[g];
+        const int M_ = uniform_i(r.M), N_ = uniform_i(r.N);
+        const int tiles_n = (N_ + BN - 1) / BN, tiles_m = (M_ + BM - 1) / BM;
+        const int lid = la - uniform_i(gp.t0[g]);
+        // grouped order: the ~64 tiles an XCD works on at once form a compact group_m x (64/group_m)
+        // block, so their A row-panels AND B column-panels together fit the XCD's 4 MiB L2
+        const int gmr = uniform_i(r.group_m);
+        const int gm_ = gmr > 0 ? gmr : 1;
+        const int per_group = gm_ * tiles_n;
+        const int first_m = (lid / per_group) * gm_;
+        const int gsz = min(tiles_m - first_m, gm_);
+        const int in_g = lid % per_group;
+        gi_ = g;
+        m0_ = (first_m + in_g % gsz) * BM;
+        n0_ = (in_g / gsz) * BN;
+    };
     const T* a_src[NA];
     const T* b_src[NB];
     int a_yx[NA];            // CONV: (y << 16) | x of the staged output pixel
+    // per-lane source addresses of the tile's operand rows (LDS-DMA: one 16-byte chunk per lane)
+    auto point = [&](int gi_, int m0_, int n0_) {
+        const GemmNT& r = gp.g[gi_];
+        const T* A_ = (const T*)uniform_ptr(r.A);
+        const T* B_ = (const T*)uniform_ptr(r.B);
+        const int M_ = uniform_i(r.M), N_ = uniform_i(r.N), lda_ = uniform_i(r.lda), ldb_ = uniform_i(r.ldb);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int r = (i * NW + wave) * SRPI + lane / CPR;
-        const int c = (lane % CPR) ^ nt_swz<BK>(r);
-        const int gr = min(m0 + r, p.M - 1);
-        a_src[i] = (const T*)p.A + (size_t)gr * p.lda + c * 8;
-        if constexpr (CONV) {
-            const int pix = gr % (p.cH * p.cW);
-            a_yx[i] = ((pix / p.cW) << 16) | (pix % p.cW);
+        for (int i = 0; i < NA; ++i) {
+            const int rr = (i * NW + wave) * SRPI + lane / CPR;
+            const int c = (lane % CPR) ^ nt_swz<BK>(rr);
+            const int gr = min(m0_ + rr, M_ - 1);
+            a_src[i] = A_ + (size_t)gr * lda_ + c * 8;
+            if constexpr (CONV) {
+                const int cH = uniform_i(r.cH), cW = uniform_i(r.cW);
+                const int pix = gr % (cH * cW);
+                a_yx[i] = ((pix / cW) << 16) | (pix % cW);
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int r = (i * NW + wave) * SRPI + lane / CPR;
-        const int c = (lane % CPR) ^ nt_swz<BK>(r);
-        const int gr = min(n0 + r, p.N - 1);
-        b_src[i] = (const T*)p.B + (size_t)gr * p.ldb + c * 8;
-    }
+        for (int i = 0; i < NB; ++i) {
+            const int rr = (i * NW + wave) * SRPI + lane / CPR;
+            const int c = (lane % CPR) ^ nt_swz<BK>(rr);
+            const int gr = min(n0_ + rr, N_ - 1);
+            b_src[i] = B_ + (size_t)gr * ldb_ + c * 8;
+        }
+    };
+    int gi, m0, n0;
+    locate(lid_all, gi, m0, n0);
+    point(gi, m0, n0);
+    GemmNT pl;
+    const GemmNT* pp = &gp.g[gi];
+    // the chosen problem, copied into SGPRs ONCE per group (see uniform_i): a dynamically indexed kernarg struct is
+    // otherwise re-read with s_load + s_waitcnt at every use (115 scalar loads in the fc1 epilogue before this)
+    auto hoist = [&](int gi_) {
+        const GemmNT& gq = gp.g[gi_];
+        {
+            pl.A = uniform_ptr(gq.A), pl.B = uniform_ptr(gq.B), pl.zero = uniform_ptr(gq.zero);
+            pl.M = uniform_i(gq.M), pl.N = uniform_i(gq.N), pl.K = uniform_i(gq.K), pl.lda = uniform_i(gq.lda), pl.ldb = uniform_i(gq.ldb);
+            pl.cH = uniform_i(gq.cH), pl.cW = uniform_i(gq.cW), pl.cCin = uniform_i(gq.cCin), pl.ckw = uniform_i(gq.ckw);
+            pl.group_m = uniform_i(gq.group_m);
+            pl.e.out = (void*)uniform_ptr(gq.e.out), pl.e.out2 = (void*)uniform_ptr(gq.e.out2);
+            pl.e.bias = (const float*)uniform_ptr(gq.e.bias), pl.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
+            pl.e.resid = (const float*)uniform_ptr(gq.e.resid), pl.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
+            pl.e.row_index = (const int32_t*)uniform_ptr(gq.e.row_index), pl.e.aux = uniform_ptr(gq.e.aux);
+            pl.e.ldo = uniform_i(gq.e.ldo), pl.e.ld2 = uniform_i(gq.e.ld2), pl.e.relu = uniform_i(gq.e.relu);
+            pl.e.drop_thresh = (uint32_t)uniform_i((int)gq.e.drop_thresh);
+            pl.e.inv_keep = uniform_f(gq.e.inv_keep), pl.e.beta = uniform_f(gq.e.beta);
+            pl.e.seed = (uint64_t)uniform_ptr((const void*)gq.e.seed);
+            pl.e.colpart = (float*)uniform_ptr(gq.e.colpart);
+            pp = &pl;
+        }
+    };
+    hoist(gi);
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-
     const int l31 = lane & 31, h = lane >> 5;
     const int swz = nt_swz<BK>(l31);
     const int a_row_off = (wm * (BM / WM) + l31) * ROWB;
     const int b_row_off = A_BYTES + (wn * (BN / WN) + l31) * ROWB;
 
-    const int nk = p.K / BK;
-    const int cpt = CONV ? (p.cCin / BK) : 1, cpad = CONV ? (p.ckw - 1) / 2 : 0;
+    const int nk = pp->K / BK;       // the groups of a launch share N and K
+    const int cpt = CONV ? (pp->cCin / BK) : 1, cpad = CONV ? (pp->ckw - 1) / 2 : 0;
     auto stage = [&](int buf, int kt) {
         char* s = smem + buf * STAGE;
         if constexpr (CONV) {
+            const GemmNT& p = *pp;
             const int tap = kt / cpt, cc = kt - tap * cpt;
             const int dy = tap / p.ckw - cpad, dx = tap % p.ckw - cpad;
             const int delta = (dy * p.cW + dx) * p.cCin + cc * BK;
@@ -328,6 +370,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
     };
+    const GemmNT& p = *pp;
+    stage(0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
     if constexpr (PP) {
         // Ping-pong schedule (8 waves, WM == 2): every K-tile is four segments separated by raw
         // s_barriers -- read fragments of k-half 0 | 16 MFMAs | read k-half 1 | 16 MFMAs -- and the
@@ -366,7 +416,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
-        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) bar();
@@ -389,7 +438,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     } else {
         static_assert(NSTG == 2, "two LDS buffers");
         // 2-deep ring: one K-tile in flight behind the one being multiplied
-        stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -419,12 +467,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
         const int gmbc = min(gmb, p.M - 1);      // edge tiles: a wave's rows may all lie past M
         f32x4 ext[NIT];
         float rs[NIT];
+        int ridx[NIT];
+        // the drop-path scale is a two-step lookup (token -> scale group -> scale): all index loads of the pass go out
+        // first, then all dependent loads, instead of eight index -> wait -> scale round trips in a row
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int gmc = gmbc + min(it * RPI + rrow, p.M - 1 - gmbc);
+            ridx[it] = (EPI == EPI_RESID && p.e.row_scale && p.e.row_index) ? p.e.row_index[gmc] : gmc;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
-            const int gmc = gmbc + rowc;
             ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
-            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[p.e.row_index ? p.e.row_index[gmc] : gmc] : 1.f;
+            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -509,9 +564,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                     pv[3] = labv;
                 }
             } else {
-                if (gm < p.M && col_ok) {
-                    const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it]);
-                    if constexpr (EPI == EPI_DGELU) csum += w;
+                const bool ok = gm < p.M && col_ok;
+                const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
+                if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) csum[j] += ok ? w[j] : 0.f;
                 }
             }
         }
