@@ -491,6 +491,8 @@ def profile_stop():
                 name = 'gemm_tn_kernel<%s>' % ('256x256' if t == 72 else '128x128')
             elif t == 73:
                 name = 'gemm_tn_multi_kernel<256x256>'
+            elif 48 <= t < 64:
+                name = f'gemm_nt_kernel<{names.get(t - 48, t - 48)},256x128>'
             elif t >= 32:
                 name = f'conv_nt_kernel<{names.get(t - 32, t - 32)}>'
             else:

@@ -78,7 +78,8 @@ const char* vlmo_last_error(void);
 int vlmo_abi_version(void);
 
 /* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  tile: -1 = pick by shape, 0 = 128x128x64
- * (two workgroups per CU), 3 = 256x256x64 with the two-wave-group ping-pong schedule (one per CU).
+ * (two workgroups per CU), 3 = 256x256x64 with the two-wave-group ping-pong schedule (one per CU),
+ * 4 = 256x128x32 (two per CU; bf16 with the bias / bias+GELU epilogues, else it falls back to 0).
  * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm
  * Mlp fc1/fc2 (vlmo.py:141-157, 195-196), the PatchEmbed conv (vlmo.py:304) and,
  * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */
@@ -209,7 +210,7 @@ int vlmo_embed_txt_bwd(const float* dx, const int64_t* ids, const float* xhat, c
                        float inv_keep, uint64_t seed, hipStream_t stream);
 
 /* Optional timing of the GEMM launches with HIP event pairs on their launch stream (bench.py's roofline).
- * stop() sums per tag: tag = epilogue id (+16 for the 256x256 tile) for vlmo_gemm_nt, 32 + epilogue for
+ * stop() sums per tag: tag = epilogue id (+16 for the 256x256 tile, +48 for the 256x128 tile) for vlmo_gemm_nt, 32 + epilogue for
  * vlmo_conv2d_nhwc, 64 / 72 for vlmo_gemm_tn (128x128 / 256x256 tiles), 73 for vlmo_gemm_tn_multi; returns the number of recorded launches. Synchronise first. */
 int vlmo_profile_start(int max_records);
 int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches);

@@ -33,7 +33,7 @@ def _close(got, ref, rtol, atol, what=''):
             f'first at {idx}: got {got[tuple(idx)].item():.6g} ref {ref[tuple(idx)].item():.6g}')
 
 
-@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('tile', [0, 3, 4])
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (300, 256, 128), (1000, 384, 768), (77, 128, 192)])
 def test_gemm_nt_exact_integers(tile, M, N, K):
     """Asymmetric small-integer operands: products and fp32 sums are exact, so any
@@ -50,7 +50,7 @@ def test_gemm_nt_exact_integers(tile, M, N, K):
     assert torch.equal(out.cpu(), ref), (out.cpu() - ref).abs().max()
 
 
-@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('tile', [0, 3, 4])
 def test_gemm_nt_bias_bf16_and_padding_rows(tile):
     M, N, K = 333, 256, 256
     A, B = _rand(M, K, seed=1), _rand(N, K, scale=0.1, seed=2)
@@ -63,6 +63,24 @@ def test_gemm_nt_bias_bf16_and_padding_rows(tile):
     out2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out2, bias=bias, relu=True, tile=tile)
     _close(out2, ref.relu(), 1 / 128, 1e-2, 'bias+relu epilogue')
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 768), (4099, 2304, 768), (77, 128, 192)])
+def test_gemm_nt_tile4_small_integers(M, N, K):
+    """The 256x128x32 tile exists for the bias / bias+GELU epilogues only (bf16 output): integer operands small enough
+    that every output is an integer below 256 in magnitude, i.e. exact in bf16 -- a fragment-layout or swizzle error of
+    this tile shape shows up as a wrong integer, ragged edges in M and N included."""
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.rand(M, K, generator=g) < 0.05).float() * torch.randint(-2, 3, (M, K), generator=g).float()
+    B = (torch.rand(N, K, generator=g) < 0.05).float() * torch.randint(-2, 3, (N, K), generator=g).float()
+    B[:, 0] = (torch.arange(N) % 3).float()
+    A[:, 0] = (torch.arange(M) % 2).float() + 1
+    bias = (torch.arange(N) % 7 - 3).float()
+    ref = A @ B.t() + bias
+    assert ref.abs().max() < 256
+    out = torch.full((M, N), float('nan'), device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nt(hip.EPI_BIAS, A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), tile=4)
+    assert torch.equal(out.float().cpu(), ref), (out.float().cpu() - ref).abs().max()
 
 
 def test_gemm_nt_f16_dtype():
@@ -401,7 +419,7 @@ def test_embed_txt_fwd_bwd():
         _close(got, leaf.grad, 1e-3, 1e-3, name)
 
 
-@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('tile', [0, 3, 4])
 @pytest.mark.parametrize('epi', ['bias_gelu', 'resid'])
 def test_gemm_nt_grouped_equals_separate_launches(tile, epi):
     """vlmo_gemm_nt_grouped (the per-modality expert FFNs in one launch) is bit-identical to one launch per
