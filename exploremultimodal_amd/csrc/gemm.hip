@@ -435,6 +435,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             bar();
         }
         if (wm == 0) bar();
+    } else if constexpr (NSTG >= 3) {
+        // NSTG-deep ring (experiment): NSTG-1 K-tiles in flight; a counted vmcnt leaves the younger ones flying across
+        // the (raw) barrier.  Buffer (kt+NSTG-1)%NSTG was last read in iteration kt-1, i.e. before every wave reached
+        // this iteration's barrier.
+        constexpr int PER = NA + NB;        // LDS-DMA instructions per wave and K-tile
+        static_assert(NSTG <= 4, "ring depth");
+#pragma unroll
+        for (int q = 1; q < NSTG - 1; ++q)
+            if (q < nk) stage(q, q);
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int ahead = min(NSTG - 2, nk - 1 - kt);       // younger tiles that may stay in flight
+            if (ahead >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NSTG - 1 < nk) stage((kt + NSTG - 1) % NSTG, kt + NSTG - 1);
+            compute(smem + (kt % NSTG) * STAGE);
+        }
     } else {
         static_assert(NSTG == 2, "two LDS buffers");
         // 2-deep ring: one K-tile in flight behind the one being multiplied
@@ -1084,7 +1109,9 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         if (tile == 0 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && K <= 1024 && N >= 2048 && Mtot >= 4096)
             tile = 4;
     }
+#ifndef VLMO_EXP_TILES
     VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4, "vlmo_gemm_nt: tile must be -1, 0, 3 or 4 (got %d)", tile);
+#endif
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
     ProfScope prof(epi + (tile == 3 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);
     // tile 4 = 256x128x32, four waves, two workgroups per CU (bf16; bias and bias+GELU epilogues only): the wide shallow
@@ -1092,6 +1119,12 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     // desynchronised workgroups per CU, finer tile quantisation: fc1 119 -> 113 us, qkv 80 -> 75 us.
     if (tile == 4)
         return launch_nt<bf16, 256, 128, 2, 2, false, 32, 2, false, (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU)>(epi, gp, stream);
+#ifdef VLMO_EXP_TILES
+    if (tile == 5 && dtype == VLMO_BF16 && epi == EPI_BIAS)
+        return launch_nt<bf16, 256, 256, 2, 4, false, 32, 3, false, (1u << EPI_BIAS)>(epi, gp, stream);
+    if (tile == 6 && dtype == VLMO_BF16 && epi == EPI_BIAS)
+        return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4, false, (1u << EPI_BIAS)>(epi, gp, stream);
+#endif
     if (dtype == VLMO_F16) {
         if (tile == 3) return launch_nt<f16, 256, 256, 2, 4, false, 64, 2, true>(epi, gp, stream);
         return launch_nt<f16, 128, 128, 2, 2>(epi, gp, stream);

@@ -24,12 +24,14 @@ def timeit(fn, reps=30):
 
 bias = torch.randn(N, device=dev)
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-for tile in (3, 0):
+for tile in [int(t) for t in os.environ.get('PROBE_TILES', '3,0').split(',')]:
     for K in (64, 128, 256, 512, 768, 1536, 3072):
         A = torch.randn(M, K, device=dev).bfloat16()
         B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         t = timeit(lambda: hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out, bias=bias, tile=tile))
         tiles = ((M + 255) // 256) * ((N + 255) // 256) if tile == 3 else ((M + 127) // 128) * ((N + 127) // 128)
-        slots = 256 if tile == 3 else 512
+        slots = 512 if tile == 0 else 256
+        if tile != 0:
+            tiles = ((M + 255) // 256) * ((N + 255) // 256)
         print(f'tile={tile} M={M} N={N} K={K:5d}: {t:7.1f} us  tiles {tiles} = {tiles / slots:.2f} rounds  '
               f'{t / (tiles / slots):6.1f} us per round  {2 * M * N * K / t / 1e6:7.1f} TF/s', flush=True)
