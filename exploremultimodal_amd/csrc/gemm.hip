@@ -1106,7 +1106,8 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             for (int q = 0; q < gp.ngroups; ++q) t256 += (long)((gp.g[q].M + 255) / 256) * ((N + 255) / 256);
             if (t256 <= 256) tile = 3;
         }
-        if (tile == 0 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && K <= 1024 && N >= 2048 && Mtot >= 4096)
+        static const bool tile4 = !getenv("VLMO_NT_TILE4") || atoi(getenv("VLMO_NT_TILE4")) != 0;     // measurement aid
+        if (tile4 && tile == 0 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && K <= 1024 && N >= 2048 && Mtot >= 4096)
             tile = 4;
     }
 #ifndef VLMO_EXP_TILES
