@@ -1137,7 +1137,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
 int group_m_default() {
     static const int v = [] {
         const char* sv = getenv("VLMO_GROUP_M");
-        return sv ? atoi(sv) : 8;
+        return sv ? atoi(sv) : 4;       // in-step sweep (bench.py, one box): 2-6 within noise of each other, 8 +0.1 ms, 16 +0.35 ms
     }();
     return v;
 }
