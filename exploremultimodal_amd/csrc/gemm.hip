@@ -378,7 +378,70 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-    if constexpr (PP) {
+    if constexpr (PP && BK == 32) {
+        // Ping-pong schedule over a 4-deep ring of 32-deep K-slices (experiment): the same two segments per slice as the
+        // BK = 64 schedule below (read fragments | 16 MFMAs, the wm == 1 waves one segment behind), but a slice is its
+        // own LDS buffer: slice h+3 is staged while slice h is multiplied, so up to three slices (96 KB) are in flight
+        // per CU and LDS-DMA instructions are issued every segment pair instead of in one burst per 64-deep tile.
+        // Counted waits: a wave waits for its part of slice h+1 before the barrier that opens that slice for the
+        // LEADING group -- the leading waves before their second barrier of slice h (slices h+2, h+3 may stay in
+        // flight), the lagging waves before their first one (h+2 may stay in flight; they issue h+3 after it).
+        static_assert(NSTG == 4 && WM == 2 && KS == 2, "ring ping-pong: 4 buffers, 2 row groups, BK = 32");
+        constexpr int PER = NA + NB;
+        v8 af[2][TM], bf[2][TN];
+        auto read32 = [&](const char* s_) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int coff = ((2 * q + h) ^ swz) << 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[q][i] = *(const v8*)(s_ + a_row_off + i * 32 * ROWB + coff);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[q][j] = *(const v8*)(s_ + b_row_off + j * 32 * ROWB + coff);
+            }
+        };
+        auto mfma32 = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[q][i], bf[q][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto wait_left = [&](int halves) {      // all but the `halves` youngest slices of this wave have landed
+            if (halves >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (halves == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const int n = nk;       // slices
+        if (n > 1) stage(1, 1);
+        if (n > 2) stage(2, 2);
+        wait_left(min(2, n - 1));
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) bar();
+        for (int hh = 0; hh < n; ++hh) {
+            const char* cur = smem + (hh & 3) * STAGE;
+            read32(cur);
+            if (wm == 1 && hh + 1 < n) wait_left(min(1, n - 2 - hh));
+            bar();
+            if (hh + 3 < n) stage((hh + 3) & 3, hh + 3);
+            mfma32();
+            if (wm == 0 && hh + 1 < n) wait_left(min(2, n - 2 - hh));
+            bar();
+        }
+        if (wm == 0) bar();
+    } else if constexpr (PP) {
         // Ping-pong schedule (8 waves, WM == 2): every K-tile is four segments separated by raw
         // s_barriers -- read fragments of k-half 0 | 16 MFMAs | read k-half 1 | 16 MFMAs -- and the
         // wm == 1 waves run ONE segment behind the wm == 0 waves (one extra barrier up front, one
@@ -1121,6 +1184,8 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     if (tile == 4)
         return launch_nt<bf16, 256, 128, 2, 2, false, 32, 2, false, (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU)>(epi, gp, stream);
 #ifdef VLMO_EXP_TILES
+    if (tile == 7 && dtype == VLMO_BF16 && epi == EPI_BIAS)
+        return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4, true, (1u << EPI_BIAS)>(epi, gp, stream);
     if (tile == 5 && dtype == VLMO_BF16 && epi == EPI_BIAS)
         return launch_nt<bf16, 256, 256, 2, 4, false, 32, 3, false, (1u << EPI_BIAS)>(epi, gp, stream);
     if (tile == 6 && dtype == VLMO_BF16 && epi == EPI_BIAS)
