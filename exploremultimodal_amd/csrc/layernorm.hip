@@ -15,48 +15,65 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const int32_t* __restrict__ rowmap, int M, int d, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
-        const f32x4* xr = (const f32x4*)(x + (size_t)m * d);
-        f32x4 v[VPL];
-        float s = 0.f;
+    // weight and bias stay in registers for all rows of the wave; TWO rows are in flight per wave (both rows' loads are
+    // issued before any arithmetic): the kernel is HBM-bound and a wave's bytes in flight are what it has to offer
+    f32x4 ww[VPL], bb[VPL];
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-            const int i = lane + 64 * j;
-            v[j] = (i < nv) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    for (int j = 0; j < VPL; ++j) {
+        const int i = min(lane + 64 * j, nv - 1);
+        ww[j] = ((const f32x4*)w)[i];
+        bb[j] = ((const f32x4*)b)[i];
+    }
+    const int stride = gridDim.x * 4;
+    for (int m0 = blockIdx.x * 4 + wave; m0 < M; m0 += 2 * stride) {
+        f32x4 v[2][VPL];
+        int mr[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            mr[r] = m0 + r * stride;
+            const f32x4* xr = (const f32x4*)(x + (size_t)min(mr[r], M - 1) * d);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) v[r][j] = xr[min(lane + 64 * j, nv - 1)];
         }
-        const float mu = wave_sum(s) / d;
-        float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-            const int i = lane + 64 * j;
-            if (i < nv) {
+        for (int r = 0; r < 2; ++r) {
+            const int m = mr[r];
+            float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float t = v[j][k] - mu;
-                    q += t * t;
+            for (int j = 0; j < VPL; ++j)
+                if (lane + 64 * j < nv) s += v[r][j][0] + v[r][j][1] + v[r][j][2] + v[r][j][3];
+            const float mu = wave_sum(s) / d;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j)
+                if (lane + 64 * j < nv) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = v[r][j][k] - mu;
+                        q += t * t;
+                    }
                 }
-            }
-        }
-        const float rs = rsqrtf(wave_sum(q) / d + eps);
-        if (lane == 0) {
-            if (mean) mean[m] = mu;
-            if (rstd) rstd[m] = rs;
-        }
-        const int om = rowmap ? rowmap[m] : m;
+            const float rs = rsqrtf(wave_sum(q) / d + eps);
+            if (m < M) {
+                if (lane == 0) {
+                    if (mean) mean[m] = mu;
+                    if (rstd) rstd[m] = rs;
+                }
+                const int om = rowmap ? rowmap[m] : m;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-            const int i = lane + 64 * j;
-            if (i < nv) {
-                const f32x4 ww = ((const f32x4*)w)[i], bb = ((const f32x4*)b)[i];
-                f32x4 o;
+                for (int j = 0; j < VPL; ++j) {
+                    const int i = lane + 64 * j;
+                    f32x4 o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (v[j][k] - mu) * rs * ww[k] + bb[k];
-                if constexpr (OUT_F32) {
-                    ((f32x4*)((float*)y + (size_t)om * d))[i] = o;
-                } else {
-                    bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-                    ((bf16x4*)((bf16*)y + (size_t)om * d))[i] = ob;
+                    for (int k = 0; k < 4; ++k) o[k] = (v[r][j][k] - mu) * rs * ww[j][k] + bb[j][k];
+                    if (i < nv) {
+                        if constexpr (OUT_F32) {
+                            ((f32x4*)((float*)y + (size_t)om * d))[i] = o;
+                        } else {
+                            bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                            ((bf16x4*)((bf16*)y + (size_t)om * d))[i] = ob;
+                        }
+                    }
                 }
             }
         }
@@ -235,7 +252,7 @@ extern "C" int vlmo_ln_fwd(const float* x, const float* w, const float* b, void*
     VLMO_CHECK_ARG(x && w && b && y, "vlmo_ln_fwd: null pointer");
     VLMO_CHECK_ARG(M > 0 && d > 0 && d % 4 == 0 && d <= 1024, "vlmo_ln_fwd: need 0 < d <= 1024, d %% 4 == 0 (d=%d, M=%d)", d, M);
     const int vpl = (d / 4 + 63) / 64;
-    const int grid = min((M + 3) / 4, 8192);
+    const int grid = min((M + 7) / 8, 8192);
 #define LNF(V)                                                                                        \
     if (out_f32)                                                                                      \
         hipLaunchKernelGGL((ln_fwd_kernel<V, true>), dim3(grid), dim3(256), 0, stream, x, w, b, y, mean, rstd, rowmap, M, d, eps); \
