@@ -1172,17 +1172,34 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         static const bool tile4 = !getenv("VLMO_NT_TILE4") || atoi(getenv("VLMO_NT_TILE4")) != 0;     // measurement aid
         if (tile4 && tile == 0 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && K <= 1024 && N >= 2048 && Mtot >= 4096)
             tile = 4;
+        // 192-row ping-pong tiles when they cut the dispatch rounds (VLMo-Large at 32 pairs: M = 8 352 = 32.6 x 256, so
+        // N = 1 024 is 132 tiles of 256x256 on 256 CUs but 176 tiles of 192x256, each 3/4 of the work)
+        static const int t192 = getenv("VLMO_NT_TILE192") ? atoi(getenv("VLMO_NT_TILE192")) : 2;       // measurement aid: 0 off, 1 only in place of 256x256, 2 in place of any
+        if (t192 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID) && K >= 1024 &&
+            (tile == 3 || t192 == 2)) {
+            long t256 = 0, t192n = 0;
+            for (int q = 0; q < gp.ngroups; ++q) {
+                t256 += (long)((gp.g[q].M + 255) / 256) * ((N + 255) / 256);
+                t192n += (long)((gp.g[q].M + 191) / 192) * ((N + 255) / 256);
+            }
+            const long e256 = ((t256 + 255) / 256) * 256, e192 = ((t192n + 255) / 256) * 192;
+            if (e192 * 10 <= e256 * 9) tile = 8;
+        }
     }
 #ifndef VLMO_EXP_TILES
-    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4, "vlmo_gemm_nt: tile must be -1, 0, 3 or 4 (got %d)", tile);
+    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4 or 8 (got %d)", tile);
 #endif
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
-    ProfScope prof(epi + (tile == 3 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);
+    if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID))) tile = 3;
+    ProfScope prof(epi + (tile == 3 || tile == 8 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);
     // tile 4 = 256x128x32, four waves, two workgroups per CU (bf16; bias and bias+GELU epilogues only): the wide shallow
     // GEMMs (qkv, fc1: K = d, N >= 3d).  1.5x the staged bytes per flop of 256x256 instead of the 2x of 128x128, still two
     // desynchronised workgroups per CU, finer tile quantisation: fc1 119 -> 113 us, qkv 80 -> 75 us.
     if (tile == 4)
         return launch_nt<bf16, 256, 128, 2, 2, false, 32, 2, false, (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU)>(epi, gp, stream);
+    if (tile == 8)
+        return launch_nt<bf16, 192, 256, 2, 4, false, 64, 2, true,
+                         (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU) | (1u << EPI_RESID)>(epi, gp, stream);
 #ifdef VLMO_EXP_TILES
     if (tile == 7 && dtype == VLMO_BF16 && epi == EPI_BIAS)
         return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4, true, (1u << EPI_BIAS)>(epi, gp, stream);

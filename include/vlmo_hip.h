@@ -79,7 +79,9 @@ int vlmo_abi_version(void);
 
 /* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  tile: -1 = pick by shape, 0 = 128x128x64
  * (two workgroups per CU), 3 = 256x256x64 with the two-wave-group ping-pong schedule (one per CU),
- * 4 = 256x128x32 (two per CU; bf16 with the bias / bias+GELU epilogues, else it falls back to 0).
+ * 4 = 256x128x32 (two per CU; bf16 with the bias / bias+GELU epilogues, else it falls back to 0),
+ * 8 = 192x256x64 ping-pong (bf16 with the bias / bias+GELU / residual epilogues, else 3): picked when its tile count
+ * needs fewer dispatch rounds than 256x256 (VLMo-Large at 32 pairs per GPU).
  * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm
  * Mlp fc1/fc2 (vlmo.py:141-157, 195-196), the PatchEmbed conv (vlmo.py:304) and,
  * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */

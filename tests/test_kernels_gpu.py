@@ -65,9 +65,10 @@ def test_gemm_nt_bias_bf16_and_padding_rows(tile):
     _close(out2, ref.relu(), 1 / 128, 1e-2, 'bias+relu epilogue')
 
 
+@pytest.mark.parametrize('tile', [4, 8])
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 768), (4099, 2304, 768), (77, 128, 192)])
-def test_gemm_nt_tile4_small_integers(M, N, K):
-    """The 256x128x32 tile exists for the bias / bias+GELU epilogues only (bf16 output): integer operands small enough
+def test_gemm_nt_tile4_small_integers(tile, M, N, K):
+    """The 256x128x32 and 192x256x64 tiles exist for a few epilogues only (bf16 output): integer operands small enough
     that every output is an integer below 256 in magnitude, i.e. exact in bf16 -- a fragment-layout or swizzle error of
     this tile shape shows up as a wrong integer, ragged edges in M and N included."""
     g = torch.Generator().manual_seed(M + N)
@@ -79,7 +80,7 @@ def test_gemm_nt_tile4_small_integers(M, N, K):
     ref = A @ B.t() + bias
     assert ref.abs().max() < 256
     out = torch.full((M, N), float('nan'), device=DEV, dtype=torch.bfloat16)
-    hip.gemm_nt(hip.EPI_BIAS, A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), tile=4)
+    hip.gemm_nt(hip.EPI_BIAS, A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), tile=tile)
     assert torch.equal(out.float().cpu(), ref), (out.float().cpu() - ref).abs().max()
 
 
@@ -419,7 +420,7 @@ def test_embed_txt_fwd_bwd():
         _close(got, leaf.grad, 1e-3, 1e-3, name)
 
 
-@pytest.mark.parametrize('tile', [0, 3, 4])
+@pytest.mark.parametrize('tile', [0, 3, 4, 8])
 @pytest.mark.parametrize('epi', ['bias_gelu', 'resid'])
 def test_gemm_nt_grouped_equals_separate_launches(tile, epi):
     """vlmo_gemm_nt_grouped (the per-modality expert FFNs in one launch) is bit-identical to one launch per
