@@ -268,20 +268,23 @@ def test_native_stack_path_equals_per_block_path(preset, B):
         assert (gs[n] - gb[n]).abs().max().item() <= tol, (n, (gs[n] - gb[n]).abs().max().item(), tol)
 
 
-def test_base_full_batch_against_oracle():
+@pytest.mark.parametrize('preset,B,out_tol,mean_tol,grad_tol', [('base', 64, 3e-2, 4e-3, 5e-2),
+                                                                ('large', 32, 4.5e-2, 6e-3, 8e-2)])
+def test_full_batch_against_oracle(preset, B, out_tol, mean_tol, grad_tol):
     """BASELINE.json configs[1] at its FULL size -- VLMo-Base, 64 pairs, 224x224 image + 64-token text (M = 16 704
     packed rows), dropout 0 -- forward + backward through the HIP path against the fp32 CPU oracle on identical
     weights and inputs.  This is the only test in which the 256x256 ping-pong NT kernels, the grouped expert
     launches, the batched no-split weight-gradient launches and the side-stream deferral run in situ at the
     benchmark's shapes.  Tolerance: as the Base golden test (3e-2 + 2e-2 |ref| on the final-LN output, mean error
-    <= 4e-3; every parameter gradient within 5 % of its norm)."""
+    <= 4e-3; every parameter gradient within 5 % of its norm).  Second case: the per-GPU workload of BASELINE.json
+    configs[3] -- VLMo-Large, 32 pairs (M = 8 352): the shapes at which the 192x256 tile is picked; tolerances of the
+    Large golden test (24 layers)."""
     from oracle import vlmo_oracle
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    model, mc = build('base')
+    model, mc = build(preset)
     for b in model.blocks[:mc.fusion_layer]:       # pretrain_mum layout (vlmo_module.py:165-167)
         del b.mlp['vl']
     model.eval()
-    B = 64
     batch = synth.synth_batch(mc, B, seed=1234)
     kw = modes(mc, batch, B)['vl']
     x, m = model.forward_features(**kw)
@@ -296,8 +299,8 @@ def test_base_full_batch_against_oracle():
     (ref * R).sum().backward()
     assert torch.equal(m.cpu(), mref)
     err = (x.detach().cpu() - ref.detach()).abs()
-    assert (err <= 3e-2 + 2e-2 * ref.detach().abs()).all(), err.max().item()
-    assert err.mean().item() <= 4e-3, err.mean().item()
+    assert (err <= out_tol + 2e-2 * ref.detach().abs()).all(), err.max().item()
+    assert err.mean().item() <= mean_tol, err.mean().item()
     worst = (0.0, '')
     for k, p in model.named_parameters():
         gr = sd[k].grad
@@ -307,5 +310,5 @@ def test_base_full_batch_against_oracle():
         assert p.grad is not None, k
         rel = (p.grad.detach().cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
         worst = max(worst, (rel, k))
-        assert rel <= 5e-2, (k, rel)
-    print('base B=64: max err %.4f mean %.5f worst grad %.4f (%s)' % (err.max().item(), err.mean().item(), *worst))
+        assert rel <= grad_tol, (k, rel)
+    print(f'{preset} B={B}: ' + 'max err %.4f mean %.5f worst grad %.4f (%s)' % (err.max().item(), err.mean().item(), *worst))
