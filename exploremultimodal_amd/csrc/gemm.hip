@@ -546,7 +546,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
     if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
     if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
-    f32x4 csum = {0.f, 0.f, 0.f, 0.f};      // EPI_DGELU: column sums of a 64-row block (fc1 bias gradient partials)
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};      // EPI_DGELU: column sums of a 32-row block (fc1 bias gradient partials)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // issue this pass's global loads first: they fly while the accumulators go through LDS
@@ -664,16 +664,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (EPI == EPI_DGELU) {
-            // column sums of du per 64-row block -> colpart[block][N]: the fc1 bias gradient is their fold, done with the
-            // other column folds of the block instead of a second pass over the [M, hidden] matrix
-            static_assert(TM % 2 == 0, "64-row partial blocks");
-            if ((i & 1) && p.e.colpart) {
+            // column sums of du per 32-row block (one epilogue pass of one wave) -> colpart[block][N]: the fc1 bias gradient
+            // is their fold, done with the other column folds of the block instead of a second pass over [M, hidden]
+            if (p.e.colpart) {
 #pragma unroll
                 for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o, 64);
-                const int blk = (gmb - 32) >> 6;
-                if (lane < LPR && col_ok && blk * 64 < p.M) *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
+                const int blk = gmb >> 5;
+                if (lane < LPR && col_ok && gmb < p.M) *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
                 csum = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -1175,7 +1174,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         // 192-row ping-pong tiles when they cut the dispatch rounds (VLMo-Large at 32 pairs: M = 8 352 = 32.6 x 256, so
         // N = 1 024 is 132 tiles of 256x256 on 256 CUs but 176 tiles of 192x256, each 3/4 of the work)
         static const int t192 = getenv("VLMO_NT_TILE192") ? atoi(getenv("VLMO_NT_TILE192")) : 2;       // measurement aid: 0 off, 1 only in place of 256x256, 2 in place of any
-        if (t192 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID) && K >= 1024 &&
+        if (t192 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU) && K >= 1024 &&
             (tile == 3 || t192 == 2)) {
             long t256 = 0, t192n = 0;
             for (int q = 0; q < gp.ngroups; ++q) {
@@ -1190,7 +1189,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4 or 8 (got %d)", tile);
 #endif
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
-    if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID))) tile = 3;
+    if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU))) tile = 3;
     ProfScope prof(epi + (tile == 3 || tile == 8 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);
     // tile 4 = 256x128x32, four waves, two workgroups per CU (bf16; bias and bias+GELU epilogues only): the wide shallow
     // GEMMs (qkv, fc1: K = d, N >= 3d).  1.5x the staged bytes per flop of 256x256 instead of the 2x of 128x128, still two
@@ -1199,7 +1198,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         return launch_nt<bf16, 256, 128, 2, 2, false, 32, 2, false, (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU)>(epi, gp, stream);
     if (tile == 8)
         return launch_nt<bf16, 192, 256, 2, 4, false, 64, 2, true,
-                         (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU) | (1u << EPI_RESID)>(epi, gp, stream);
+                         (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU) | (1u << EPI_RESID) | (1u << EPI_DGELU)>(epi, gp, stream);
 #ifdef VLMO_EXP_TILES
     if (tile == 7 && dtype == VLMO_BF16 && epi == EPI_BIAS)
         return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4, true, (1u << EPI_BIAS)>(epi, gp, stream);

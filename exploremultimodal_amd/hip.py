@@ -121,7 +121,7 @@ _SIGS = {
 }
 
 _lib = None
-ABI_VERSION = 2      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
+ABI_VERSION = 3      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
 
 def lib():
     """Load (once) and return the C-ABI library; raise loudly if it is missing."""

@@ -69,8 +69,8 @@ typedef struct VlmoEpilogue {
     float inv_keep;         /* 1 / (1 - p)                                  */
     float beta;
     uint64_t seed;
-    float* colpart;         /* VLMO_EPI_DGELU: [ceil(M/64), N] fp32 or NULL: row b = column sums of  */
-                            /* the values written to out rows [64b, 64b+64) -- the fc1 bias gradient */
+    float* colpart;         /* VLMO_EPI_DGELU: [ceil(M/32), N] fp32 or NULL: row b = column sums of  */
+                            /* the values written to out rows [32b, 32b+32) -- the fc1 bias gradient */
                             /* is the fold of these rows (vlmo_colwork_multi kind 0); plain stores   */
 } VlmoEpilogue;
 
@@ -80,7 +80,7 @@ int vlmo_abi_version(void);
 /* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  tile: -1 = pick by shape, 0 = 128x128x64
  * (two workgroups per CU), 3 = 256x256x64 with the two-wave-group ping-pong schedule (one per CU),
  * 4 = 256x128x32 (two per CU; bf16 with the bias / bias+GELU epilogues, else it falls back to 0),
- * 8 = 192x256x64 ping-pong (bf16 with the bias / bias+GELU / residual epilogues, else 3): picked when its tile count
+ * 8 = 192x256x64 ping-pong (bf16 with the bias / bias+GELU / residual / GELU-derivative epilogues, else 3): picked when its tile count
  * needs fewer dispatch rounds than 256x256 (VLMo-Large at 32 pairs per GPU).
  * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm
  * Mlp fc1/fc2 (vlmo.py:141-157, 195-196), the PatchEmbed conv (vlmo.py:304) and,
