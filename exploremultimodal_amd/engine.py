@@ -641,30 +641,35 @@ class EmbedFn(torch.autograd.Function):
         B, T, P = pl.B, pl.T, pl.P
         drop, seed = meta['drop'], meta['seed']
         dx = dx.contiguous()
-        z = lambda t: torch.zeros_like(t, dtype=torch.float32)
         g = [None] * 11   # patch_w, patch_b, cls, mask, pos, type, word, tpos, btype, ln_w, ln_b
-        dtype_emb = z(type_emb)
+        # every parameter gradient of the embeddings is a view of ONE zero-filled buffer (one fill launch instead of eleven)
+        npatch = P - 1 if P else 0
+        shapes = [tuple(type_emb.shape)]
+        if T:
+            shapes += [tuple(word.shape), (meta['tpos_rows'], d), (2, d), (d,), (d,)]
+        if P:
+            shapes += [(d,), (d,), (P, d), (d, saved['img'].shape[1]), (d,)]
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            views.append(flat[o:o + n].view(sh))
+            o += n
+        dtype_emb = views[0]
+        k = 1
         if T:
             xhat, rstd = saved['txt']
-            dword = z(word)
-            dtpos = torch.zeros((T, d), dtype=torch.float32, device=dev)
-            dbtype = torch.zeros((2, d), dtype=torch.float32, device=dev)
-            dlnw, dlnb = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
-            hip.embed_txt_bwd(dx[:pl.nt], meta['ids'], xhat, rstd, ln_w, dword, dtpos, dbtype[0], dlnw, dlnb,
+            dword, dtpos_full, dbtype, dlnw, dlnb = views[k:k + 5]
+            k += 5
+            hip.embed_txt_bwd(dx[:pl.nt], meta['ids'], xhat, rstd, ln_w, dword, dtpos_full[:T], dbtype[0], dlnw, dlnb,
                               dtype_emb[0], B, T, d, drop=drop, seed=seed + 1)
-            g[6], g[8], g[9], g[10] = dword, dbtype, dlnw, dlnb
-            g[7] = dtpos if meta['tpos_rows'] == T else torch.cat(
-                [dtpos, torch.zeros((meta['tpos_rows'] - T, d), device=dev)])
+            g[6], g[7], g[8], g[9], g[10] = dword, dtpos_full, dbtype, dlnw, dlnb
         if P:
-            npatch = P - 1
             patches = saved['img']
             dproj = torch.empty((B * npatch, d), dtype=torch.bfloat16, device=dev)
-            dcls, dmask = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
-            dpos = torch.zeros((P, d), device=dev)
+            dcls, dmask, dpos, dpw, dpb = views[k:k + 5]
             hip.embed_img_bwd(dx[pl.nt:], meta['masked'], dproj, dcls, dmask, dpos, dtype_emb[meta['img_type']],
                               B, npatch, d, drop=drop, seed=seed + 2)
-            dpw = torch.zeros((d, patches.shape[1]), device=dev)
-            dpb = torch.zeros(d, device=dev)
             hip.gemm_tn(dproj, patches, dpw, B * npatch, d, patches.shape[1])
             hip.colsum(dproj, dpb, B * npatch, d)
             g[0], g[1] = dpw.view_as(patch_w), dpb
