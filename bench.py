@@ -9,6 +9,7 @@ For N > 1 every rank runs the same per-GPU batch (weak scaling) and gradients ar
 averaged over RCCL (exploremultimodal_amd/dp.py).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W        (starts its own N ranks when no launcher did)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -23,10 +24,84 @@ from functools import partial
 
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # see exploremultimodal_amd/__init__.py
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def spawn_ranks(n, cmd, port=None, env=None, timeout=None):
+    """`python bench.py --gpus N` from a plain shell (no launcher, WORLD_SIZE unset): start one child process per rank
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what utils/utils.py:298-334
+    `init_distributed_mode` reads from the launcher's environment), relay rank 0's stdout (the ONE JSON line) and
+    return the first non-zero exit code (the other ranks are then terminated).  The parent never touches the GPU:
+    this runs before torch is imported, and a process that has initialised HIP is never re-exec'ed."""
+    import socket
+    import subprocess
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # rank 0 owns stdout; the other ranks print nothing there by contract, anything they do print goes to stderr
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc, t_end = 0, (time.time() + timeout) if timeout else None
+    out0 = b''
+    try:
+        import threading
+        buf = []
+        rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        rd.start()
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                c = procs[r].poll()
+                if c is not None:
+                    alive.discard(r)
+                    if c != 0 and rc == 0:
+                        rc = c
+            if rc != 0 or (t_end and time.time() > t_end):
+                if rc == 0:
+                    rc = 124
+                break
+            time.sleep(0.05)
+        for r in alive:             # a rank failed (or the time limit passed): end exactly the children started here
+            procs[r].terminate()
+        for r in alive:
+            try:
+                procs[r].wait(10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        rd.join(10)
+        out0 = buf[0] if buf else b''
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    if rc == 0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out0.decode())
+    return rc
+
+
+def _wanted_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith('--gpus='):
+            return int(a.split('=', 1)[1])
+    return 1
+
+
+if __name__ == '__main__' and 'WORLD_SIZE' not in os.environ and _wanted_gpus(sys.argv[1:]) > 1:
+    sys.exit(spawn_ranks(_wanted_gpus(sys.argv[1:]), [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
+import torch
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
@@ -146,9 +221,10 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    if args.gpus != world:       # a launcher set WORLD_SIZE: the environment is authoritative (utils/utils.py:298-334)
+        if rank == 0:
+            print(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} ranks', file=sys.stderr)
+        args.gpus = world
     if args.rehearse_gloo:
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -284,28 +360,25 @@ def main():
             v_only = 2 * (P - 1) * mc.in_chans * mc.patch_size ** 2 * d_ + L_ * blk(P)
             l_only = L_ * blk(T_)
             fl = 3 * (4 * fl // 3 + 2 * v_only + l_only) + int(52.119e9)      # + dVAE forward per image
-        # dominant kernel: per-symbol totals from the event pairs recorded in the timed region
+        # per-symbol totals from the HIP-event pairs recorded in the timed region (hip.profile_start / _stop)
         per = {sym: [sec, flops, n] for sym, (sec, flops, n) in prof.items()}
-        # dominant kernel = the symbol that carries the largest share of the step's algorithmic flops (the batched
-        # weight-gradient launch: 32 %).  Ranking by event time is unstable in the overlapped step: a main-stream launch
-        # that starts beside a weight-gradient launch queues for compute units (dgrad_fc2: 136 us alone, 281 us then)
-        dom = max(per.items(), key=lambda kv: kv[1][1]) if per else None
-        roof = None
-        if dom:
-            sym, (tsec, flops, n) = dom
+        import re
+        tf = _latest_profile('traffic.json')
+        try:
+            pmc = json.load(open(tf)) if tf else None
+        except (OSError, ValueError):
+            pmc = None
+
+        def roof_of(item):
+            sym, (tsec, flops, n) = item
             ach = flops / tsec / 1e12
-            roof = {'bound': 'mfma', 'kernel': sym, 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-                    'launches_per_step': n // args.steps, 'avg_launch_us': round(tsec / n * 1e6, 2),
-                    'flops_per_launch': round(flops / n)}
-        pmc = None
-        if roof is not None:        # HBM bytes per launch from the committed PMC passes of this same command
+            r = {'bound': 'mfma', 'kernel': sym, 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS,
+                 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                 'launches_per_step': n // args.steps, 'avg_launch_us': round(tsec / n * 1e6, 2),
+                 'flops_per_launch': round(flops / n), 's_per_step': round(tsec / args.steps, 6)}
+            # HBM bytes per launch: from the committed PMC passes of this same command (another run: flagged as such)
             try:
-                import re
-                tf = _latest_profile('traffic.json')
-                pmc = json.load(open(tf))
-                tr = pmc['kernels']
-                m = re.match(r'(gemm_[a-z_]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', roof['kernel'])
+                m = re.match(r'(gemm_[a-z_]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', sym)
                 epi = {'bias': 0, 'bias_gelu': 1, 'resid': 2, 'dgelu': 3, 'f32': 4, 'dual': 5, 'argmax': 6}
                 if 'multi' in m.group(1):
                     pat = m.group(1)
@@ -313,13 +386,21 @@ def main():
                     pat = f'{m.group(1)}IDF16bLi{m.group(3)}ELi{m.group(4)}ELi\\dELi\\dE'
                     if m.group(2):
                         pat += f'Li{epi[m.group(2)]}E'
-                for k, v in tr.items():
+                for k, v in pmc['kernels'].items():
                     if re.search(pat, k):
-                        roof['traffic'] = round(v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
-                        roof['traffic_source'] = os.path.relpath(tf, ROOT)
+                        r['traffic'] = round(v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
+                        r['traffic_measured_in_run'] = False
+                        r['traffic_source'] = os.path.relpath(tf, ROOT)
                         break
-            except (OSError, KeyError, ValueError, AttributeError, TypeError):
+            except (KeyError, ValueError, AttributeError, TypeError):
                 pass
+            return r
+
+        # `roofline` = the kernel symbol with the largest ELAPSED share of the step (event time on its launch stream; in
+        # the overlapped step this includes time a launch waits for compute units the other stream holds, so it is the
+        # lower of the two rates one could quote); `roofline_by_flops` = the symbol that carries the most flops
+        roof = roof_of(max(per.items(), key=lambda kv: kv[1][0])) if per else None
+        roof_fl = roof_of(max(per.items(), key=lambda kv: kv[1][1])) if per else None
         out = {
             'metric': 'image-text pairs/sec fwd+bwd, VLMo-Base, 1/2/4/8 MI355X; % bf16 MFMA roofline',
             'value': round(pairs, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
@@ -338,16 +419,21 @@ def main():
             'step_mfma_frac': round(fl * B * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
             'flops_per_pair': fl,
             'roofline': roof,
+            'roofline_by_flops': roof_fl,
             'kernels': {k: {'s_per_step': round(v[0] / args.steps, 6), 'tflops': round(v[1] / v[0] / 1e12, 1)}
                         for k, v in per.items()},
         }
-        # north_star: "rocprof HBM GB/s and MFMA-busy counters reported against chip peak" -- whole-step figures from
-        # the committed PMC passes of this same command (profiles/rNN_*traffic.json, tools/summarize_pmc.py)
-        if pmc is not None and 'step' in pmc:
-            out['hbm_gbs'] = pmc['step'].get('hbm_gbs')
-            out['hbm_frac'] = round(pmc['step'].get('hbm_gbs', 0) / PEAK_HBM_GBS, 4) if pmc['step'].get('hbm_gbs') else None
-            out['mfma_busy'] = pmc['step'].get('mfma_busy')
-            out['pmc_source'] = os.path.relpath(_latest_profile('traffic.json'), ROOT)
+        # north_star: "rocprof HBM GB/s and MFMA-busy counters reported against chip peak": whole-step figures of the
+        # committed PMC passes of this same command (profiles/rNN_traffic.json, tools/profile_round.sh +
+        # tools/summarize_pmc.py).  They were NOT measured by this run: they sit in their own block with the profile's
+        # step time, and are dropped when that differs from this run's by more than 10 % (another build or workload).
+        if pmc is not None and 'step' in pmc and args.objective == 'vl' and args.preset == 'base' and B == 64:
+            pms = pmc.get('ms_per_step_unprofiled')
+            if pms and abs(pms - ms) / ms <= 0.10:
+                out['from_profile'] = {'measured_in_run': False, 'source': os.path.relpath(tf, ROOT),
+                                       'profile_ms_per_step': pms, 'hbm_gbs': pmc['step'].get('hbm_gbs'),
+                                       'hbm_frac': round(pmc['step'].get('hbm_gbs', 0) / PEAK_HBM_GBS, 4),
+                                       'mfma_busy': pmc['step'].get('mfma_busy')}
         out['host_enqueue_ms'] = round(host_ms, 3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.preset)

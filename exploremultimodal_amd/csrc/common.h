@@ -37,6 +37,19 @@ void vlmo_set_error(const char* fmt, ...);
         }                                                                   \
     } while (0)
 
+// One-time setup per DEVICE (hipFuncSetAttribute for a kernel's dynamic-LDS limit): a process may drive several GPUs,
+// and a function attribute set on one device is not set on another.
+struct DeviceOnce {
+    uint64_t done = 0;      // bit d: already done on device d (< 64 devices per process)
+    bool first() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        const uint64_t old = __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+        return (old & bit) == 0;
+    }
+};
+
 // ---- column reductions -------------------------------------------------------
 // Column sums over the token dimension (bias / gamma / LayerNorm-weight gradients)
 // are done in two stages: each workgroup writes its partial row to a caller-owned

@@ -378,70 +378,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-    if constexpr (PP && BK == 32) {
-        // Ping-pong schedule over a 4-deep ring of 32-deep K-slices (experiment): the same two segments per slice as the
-        // BK = 64 schedule below (read fragments | 16 MFMAs, the wm == 1 waves one segment behind), but a slice is its
-        // own LDS buffer: slice h+3 is staged while slice h is multiplied, so up to three slices (96 KB) are in flight
-        // per CU and LDS-DMA instructions are issued every segment pair instead of in one burst per 64-deep tile.
-        // Counted waits: a wave waits for its part of slice h+1 before the barrier that opens that slice for the
-        // LEADING group -- the leading waves before their second barrier of slice h (slices h+2, h+3 may stay in
-        // flight), the lagging waves before their first one (h+2 may stay in flight; they issue h+3 after it).
-        static_assert(NSTG == 4 && WM == 2 && KS == 2, "ring ping-pong: 4 buffers, 2 row groups, BK = 32");
-        constexpr int PER = NA + NB;
-        v8 af[2][TM], bf[2][TN];
-        auto read32 = [&](const char* s_) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int coff = ((2 * q + h) ^ swz) << 4;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[q][i] = *(const v8*)(s_ + a_row_off + i * 32 * ROWB + coff);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[q][j] = *(const v8*)(s_ + b_row_off + j * 32 * ROWB + coff);
-            }
-        };
-        auto mfma32 = [&]() {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[q][i], bf[q][j], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto bar = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto wait_left = [&](int halves) {      // all but the `halves` youngest slices of this wave have landed
-            if (halves >= 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-            else if (halves == 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        const int n = nk;       // slices
-        if (n > 1) stage(1, 1);
-        if (n > 2) stage(2, 2);
-        wait_left(min(2, n - 1));
-        __builtin_amdgcn_s_barrier();
-        if (wm == 1) bar();
-        for (int hh = 0; hh < n; ++hh) {
-            const char* cur = smem + (hh & 3) * STAGE;
-            read32(cur);
-            if (wm == 1 && hh + 1 < n) wait_left(min(1, n - 2 - hh));
-            bar();
-            if (hh + 3 < n) stage((hh + 3) & 3, hh + 3);
-            mfma32();
-            if (wm == 0 && hh + 1 < n) wait_left(min(2, n - 2 - hh));
-            bar();
-        }
-        if (wm == 0) bar();
-    } else if constexpr (PP) {
+    if constexpr (PP) {
         // Ping-pong schedule (8 waves, WM == 2): every K-tile is four segments separated by raw
         // s_barriers -- read fragments of k-half 0 | 16 MFMAs | read k-half 1 | 16 MFMAs -- and the
         // wm == 1 waves run ONE segment behind the wm == 0 waves (one extra barrier up front, one
@@ -498,31 +435,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             bar();
         }
         if (wm == 0) bar();
-    } else if constexpr (NSTG >= 3) {
-        // NSTG-deep ring (experiment): NSTG-1 K-tiles in flight; a counted vmcnt leaves the younger ones flying across
-        // the (raw) barrier.  Buffer (kt+NSTG-1)%NSTG was last read in iteration kt-1, i.e. before every wave reached
-        // this iteration's barrier.
-        constexpr int PER = NA + NB;        // LDS-DMA instructions per wave and K-tile
-        static_assert(NSTG <= 4, "ring depth");
-#pragma unroll
-        for (int q = 1; q < NSTG - 1; ++q)
-            if (q < nk) stage(q, q);
-        for (int kt = 0; kt < nk; ++kt) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int ahead = min(NSTG - 2, nk - 1 - kt);       // younger tiles that may stay in flight
-            if (ahead >= 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-            else if (ahead == 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + NSTG - 1 < nk) stage((kt + NSTG - 1) % NSTG, kt + NSTG - 1);
-            compute(smem + (kt % NSTG) * STAGE);
-        }
     } else {
         static_assert(NSTG == 2, "two LDS buffers");
         // 2-deep ring: one K-tile in flight behind the one being multiplied
@@ -1023,11 +935,9 @@ int launch_nt(int epi, GemmNTGroups& p, hipStream_t st) {
     } else {                                                                                   \
         auto k = gemm_nt_kernel<T, BM, BN, WM, WN, E, CONV, BK, NSTG, PP>;                                        \
         if (LDS > 65536) {                                                                     \
-            static bool attr_set = false;                                                      \
-            if (!attr_set) {                                                                   \
+            static DeviceOnce attr_set;        /* per kernel instantiation AND per device */      \
+            if (attr_set.first())                                                              \
                 (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-                attr_set = true;                                                               \
-            }                                                                                  \
         }                                                                                      \
         hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                        \
     } break;
@@ -1185,9 +1095,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             if (e192 * 10 <= e256 * 9) tile = 8;
         }
     }
-#ifndef VLMO_EXP_TILES
     VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4 or 8 (got %d)", tile);
-#endif
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
     if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU))) tile = 3;
     ProfScope prof(epi + (tile == 3 || tile == 8 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);
@@ -1199,14 +1107,6 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     if (tile == 8)
         return launch_nt<bf16, 192, 256, 2, 4, false, 64, 2, true,
                          (1u << EPI_BIAS) | (1u << EPI_BIAS_GELU) | (1u << EPI_RESID) | (1u << EPI_DGELU)>(epi, gp, stream);
-#ifdef VLMO_EXP_TILES
-    if (tile == 7 && dtype == VLMO_BF16 && epi == EPI_BIAS)
-        return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4, true, (1u << EPI_BIAS)>(epi, gp, stream);
-    if (tile == 5 && dtype == VLMO_BF16 && epi == EPI_BIAS)
-        return launch_nt<bf16, 256, 256, 2, 4, false, 32, 3, false, (1u << EPI_BIAS)>(epi, gp, stream);
-    if (tile == 6 && dtype == VLMO_BF16 && epi == EPI_BIAS)
-        return launch_nt<bf16, 256, 256, 2, 4, false, 32, 4, false, (1u << EPI_BIAS)>(epi, gp, stream);
-#endif
     if (dtype == VLMO_F16) {
         if (tile == 3) return launch_nt<f16, 256, 256, 2, 4, false, 64, 2, true>(epi, gp, stream);
         return launch_nt<f16, 128, 128, 2, 2>(epi, gp, stream);
@@ -1312,11 +1212,10 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
     if (pl.big) {
         constexpr int LDS = 2 * 4 * 64 * 256;
-        static bool attr = false;
-        if (!attr) {
+        static DeviceOnce attr;
+        if (attr.first()) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr = true;
         }
         if (dtype == VLMO_F16)
             hipLaunchKernelGGL((gemm_tn_kernel<f16, 256, 256, 2, 4, true>), grid, dim3(512), LDS, stream, p);
@@ -1344,12 +1243,11 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
 extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, hipStream_t stream) {
     VLMO_CHECK_ARG(probs && n >= 1, "vlmo_gemm_tn_multi: no problems");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn_multi: dtype must be bf16 or f16");
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.first()) {
         constexpr int LDS = 2 * 4 * 64 * 256;
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
     }
     for (int q0 = 0, nq = 0; q0 < n; q0 += nq) {
         // one launch = as many of the remaining problems as fit the problem table and the placement table

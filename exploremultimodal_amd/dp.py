@@ -54,6 +54,8 @@ class _Bucket:
         self.work = None
         self.launched = False
         self.used = []
+        self.has_grad = False   # reduced in the current accumulation window (see GradReducer.prepare)
+        self.had = []
 
 
 class _Arena:
@@ -87,6 +89,7 @@ class _SinkBucket:
         self.reduced = False    # a collective has been issued for this step's contents
         self.work = None
         self.shard = None
+        self.has_grad = False   # a collective has been issued for it in the current accumulation window
 
 
 def _all_reduce(comm, pg, world, rs_ag):
@@ -184,6 +187,15 @@ class GradReducer:
                 used.add(v)
             for nxt, _ in fn.next_functions:
                 stack.append(nxt)
+        if getattr(self, '_window_done', True):
+            # first backward of a new accumulation window (the previous finish() was an update step): nothing has been
+            # reduced yet.  zero.ZeroAdam reads these flags: a bucket that receives no gradient in this window (every pass
+            # feeding it dropped, modality absent) must not be stepped with the PREVIOUS window's shard.
+            for b in self.buckets:
+                b.has_grad, b.had = False, [False] * len(b.params)
+            for sb in self.sinks.values():
+                sb.has_grad = False
+            self._window_done = False
         for b in self.buckets:
             # parameters fed by an engine sink bucket never fire the accumulate hook
             b.used = [(p in used) and (id(p) not in self._sink_params) for p in b.params]
@@ -306,10 +318,10 @@ class GradReducer:
             if comm.data_ptr() != flat.data_ptr():
                 flat.copy_(comm)
         for sb in sbs:
-            sb.work, sb.unpacked, sb.reduced = work, True, True
+            sb.work, sb.unpacked, sb.reduced, sb.has_grad = work, True, True, True
 
     def _launch_sink(self, sb):
-        sb.reduced = True
+        sb.reduced = sb.has_grad = True
         # everything on the communication stream (ordered after the block backward that just finished on the
         # current stream): the pack would otherwise sit in the dgrad chain's critical path 30 times per step
         if self.on_gpu:
@@ -319,8 +331,16 @@ class GradReducer:
             from contextlib import nullcontext
             ctxm = nullcontext()
         with ctxm:
+            src = sb.comm
             if sb.comm is not sb.flat:
                 torch.mul(sb.flat, 1.0 / self.world, out=sb.comm)   # ONE pass: 1/world scaling + fp32 -> bf16 pack
+            elif self.reduce_scatter:
+                # fp32 communication + gradient partition: the reduce-scatter writes only the shard, so `flat` stays the
+                # LOCAL accumulator that the next micro-step of a gradient-accumulation window adds to -- it must never
+                # be scaled in place (it would carry g1 / W into the next pack: (g1 / W + g2) / W)
+                if getattr(sb, 'rs_pack', None) is None:
+                    sb.rs_pack = torch.empty_like(sb.flat)
+                src = torch.mul(sb.flat, 1.0 / self.world, out=sb.rs_pack)
             else:
                 sb.flat.mul_(1.0 / self.world)
             if self.reduce_scatter:
@@ -330,7 +350,7 @@ class GradReducer:
                     sb.shard_comm = torch.empty(n, dtype=sb.comm.dtype, device=self.device)
                     sb.shard32 = sb.shard_comm if sb.comm.dtype == torch.float32 else torch.empty(
                         n, dtype=torch.float32, device=self.device)
-                sb.work = dist.reduce_scatter_tensor(sb.shard_comm, sb.comm, group=self.pg, async_op=True)
+                sb.work = dist.reduce_scatter_tensor(sb.shard_comm, src, group=self.pg, async_op=True)
             else:
                 sb.work = _all_reduce(sb.comm, self.pg, self.world, self.rs_ag)
             if self.on_gpu:
@@ -371,7 +391,9 @@ class GradReducer:
             b.had = []
             for p, off, u in zip(b.params, b.offsets, b.used):
                 v = b.comm[off:off + p.numel()]
-                has = u and p.grad is not None
+                # gradient partition: p.grad stays the rank-local sum over the micro-steps of an accumulation window, so a
+                # parameter an EARLIER micro-step touched is packed again even when this one did not use it
+                has = (u or self.reduce_scatter) and p.grad is not None
                 if has:
                     torch.mul(p.grad.reshape(-1), inv, out=v)
                     if self.on_gpu:
@@ -391,7 +413,7 @@ class GradReducer:
             if self.on_gpu:
                 b.work.wait()           # orders the communication stream after the collective (no host block)
                 self._unpack(b)
-        b.launched = True
+        b.launched = b.has_grad = True
 
     def _unpack(self, b):
         if self.reduce_scatter:
@@ -411,6 +433,7 @@ class GradReducer:
         if not self._armed:
             raise RuntimeError('GradReducer.finish() without prepare()')
         self._armed = False
+        self._window_done = not accumulate
         inv = 1.0 / self.world
         for b in self.buckets:
             if b.expected == 0:

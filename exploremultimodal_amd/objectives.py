@@ -55,11 +55,15 @@ def compute_accuracy(logits, target):
 
 
 def _vocab_head_loss(model, head, feats, labels, vocab):
-    """Loss / logits / accuracy of a vocabulary head on gathered rows.  ``config.train.fused_ce``: HIP path without
-    logits in HBM (heads.LinearCrossEntropyFn; `*_logits` is then None); else the logits are returned as the
-    reference does (objectives.py:57-68, 571-582).  With no rows the loss is the python float 0."""
+    """Loss / logits / accuracy of a vocabulary head on gathered rows.  ``config.train.fused_ce`` or
+    ``config.train.return_logits = False``: HIP path without logits in HBM (heads.LinearCrossEntropyFn; `*_logits` is
+    then None); else the logits are returned as the reference does (objectives.py:57-68, 571-582).  With no rows the loss is the python float 0."""
     n = labels.numel()
-    fused = bool(getattr(model.config.train, 'fused_ce', False))
+    tr = model.config.train
+    # the HIP path runs whenever the caller does not need the logits back: `fused_ce` asks for it outright,
+    # `return_logits = False` says the [rows, vocabulary] outputs of the reference contract are not wanted
+    # (default True: the reference's output dict, models/vlmo/objectives.py:70-77,584-590)
+    fused = bool(getattr(tr, 'fused_ce', False)) or not bool(getattr(tr, 'return_logits', True))
     if n == 0:
         return 0., (None if fused else head(feats)), torch.tensor(0, device=labels.device), 0
     if fused:

@@ -263,19 +263,3 @@ class NativeScalerWithGradNormCount:
 
     def load_state_dict(self, state_dict):
         pass
-
-
-def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0,
-                     warmup_steps=-1):
-    """Per-iteration value table (utils/utils.py:399-424): linear warm-up (only when ``warmup_epochs > 0``, its
-    length overridden by ``warmup_steps``), then a half cosine from ``base_value`` to ``final_value``."""
-    import numpy as np
-    warmup_iters = warmup_epochs * niter_per_ep
-    if warmup_steps > 0:
-        warmup_iters = warmup_steps
-    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
-    n = epochs * niter_per_ep - warmup_iters
-    rest = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)])
-    schedule = np.concatenate((warm, rest))
-    assert len(schedule) == epochs * niter_per_ep
-    return schedule

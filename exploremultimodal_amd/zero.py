@@ -66,6 +66,8 @@ class ZeroAdam:
         self.parts = None
         self._tab = None
         self.last_ctl = None
+        self._pending_state = None
+        self._pstep = {}            # id(parameter) -> optimizer steps taken (torch.optim.AdamW keeps one per parameter)
 
     # ------------------------------------------------------------------------------------------ partition
     def _group_of(self):
@@ -94,20 +96,46 @@ class ZeroAdam:
         torch.autograd.graph.increment_version([p for pt in parts for p, _, _ in pt.entries])
         self.parts = parts
         self._tab = None
+        if self._pending_state is not None:
+            self._apply_state(self._pending_state)
+            self._pending_state = None
 
-    def _table(self):
-        """Device tables of the multi-tensor kernels: one entry per (bucket slice n parameter) overlap."""
-        dev = self.reducer.device
-        ent = []        # (p_ptr, g_ptr, m_ptr, v_ptr, numel, group)
+    @staticmethod
+    def _part_key(pt):
+        """Identity of a partition entry across processes: the bucket's padded size and its parameters' (offset, numel)."""
+        return [int(pt.padded)] + [[int(off), int(p.numel())] for p, off, _ in pt.entries]
+
+    def _apply_state(self, sd):
+        saved = sd['parts']
+        if len(saved) != len(self.parts):
+            raise ValueError(f'ZeroAdam state has {len(saved)} partition entries, this run built {len(self.parts)}')
+        for i, (pt, st) in enumerate(zip(self.parts, saved)):
+            if 'key' in st and st['key'] != self._part_key(pt):
+                raise ValueError(f'ZeroAdam state entry {i} does not describe the same bucket (saved {st["key"][:3]}..., '
+                                 f'built {self._part_key(pt)[:3]}...): same model, objectives and world size are required')
+            if st['m'].numel() != pt.m.numel():
+                raise ValueError(f'ZeroAdam state entry {i}: slice of {st["m"].numel()} elements, expected {pt.m.numel()}')
+            pt.m.copy_(st['m'])
+            pt.v.copy_(st['v'])
+            for (p, _, _), n_ in zip(pt.entries, st.get('steps', [int(sd['step'])] * len(pt.entries))):
+                self._pstep[id(p)] = int(n_)
+
+    def _entries(self):
+        """(p_ptr, g_ptr, m_ptr, v_ptr, numel, group, param) per (bucket slice n parameter) overlap that received a
+        gradient in the current accumulation window."""
+        ent = []
         for pt in self.parts:
             shard = getattr(pt.bucket, 'shard32', None)
-            if shard is None:
-                continue            # this bucket has never been reduced (its parameters got no gradient yet)
+            # `shard32` is a persistent buffer: it still holds the PREVIOUS window's gradient when nothing fed the bucket in
+            # this one (every pass that uses it dropped from the loss, modality absent).  torch.optim / FusedAdam skip
+            # `grad is None`; so does this: only buckets reduced in the current window (GradReducer.prepare / _launch*)
+            if shard is None or not getattr(pt.bucket, 'has_grad', False):
+                continue
             # parameters of a hook bucket that received no gradient in this step (an objective skipped; unused heads)
             # are left alone, as torch.optim / FusedAdam skip `grad is None` (no moment decay, no weight decay)
             had = getattr(pt.bucket, 'had', None)
             skip = set()
-            if had is not None:
+            if had is not None and hasattr(pt.bucket, 'offsets'):
                 skip = {id(p) for p, h in zip(pt.bucket.params, had) if not h}
             for p, off, gi in pt.entries:
                 if id(p) in skip:
@@ -116,10 +144,20 @@ class ZeroAdam:
                 if lo >= hi:
                     continue
                 ent.append((pt.pflat.data_ptr() + 4 * lo, shard.data_ptr() + 4 * (lo - pt.lo),
-                            pt.m.data_ptr() + 4 * (lo - pt.lo), pt.v.data_ptr() + 4 * (lo - pt.lo), hi - lo, gi))
+                            pt.m.data_ptr() + 4 * (lo - pt.lo), pt.v.data_ptr() + 4 * (lo - pt.lo), hi - lo, gi, p))
+        return ent
+
+    def _table(self, ent):
+        """Device tables of the multi-tensor kernels for the entries `ent` (cached by their addresses)."""
+        dev = self.reducer.device
         sig = tuple(e[:5] for e in ent)
-        if self._tab is not None and self._tab['sig'] == sig:
-            return self._tab
+        if self._tab is None:
+            self._tab = {}
+        tab = self._tab.get(sig)
+        if tab is not None:
+            return tab
+        if len(self._tab) > 8:          # the sets of parameters stepping together change rarely
+            self._tab.clear()
         nt = len(ent)
         chunk_tensor, chunk_start = [], []
         for t, e in enumerate(ent):
@@ -147,7 +185,7 @@ class ZeroAdam:
             tl.chunk_tensor = tab['dev_c'].data_ptr()
             tl.n_chunks, tl.chunk = nc, CHUNK
             tab['tl'] = tl
-        self._tab = tab
+        self._tab[sig] = tab
         return tab
 
     # ------------------------------------------------------------------------------------------ kernels
@@ -168,12 +206,8 @@ class ZeroAdam:
         elif any(sb not in [pt.bucket for pt in self.parts] for sb in red.sinks.values()):
             raise RuntimeError('new gradient buckets appeared after the partition was built: run one backward of '
                                'every objective before the first ZeroAdam.step()')
-        tab = self._table()
-        nt = tab['nt']
-        lrwd = torch.tensor([self.param_groups[e[5]]['lr'] for e in tab['ent']] +
-                            [self.param_groups[e[5]]['weight_decay'] for e in tab['ent']], dtype=torch.float32)
-        if nt:
-            tab['dev_f'][:2 * nt].copy_(lrwd, non_blocking=True)
+        ent = self._entries()
+        tab = self._table(ent)          # every stepping entry: the gradient norm covers all of them
         self.step_count += 1
         ctl = None
         if clip_grad is not None:
@@ -187,20 +221,35 @@ class ZeroAdam:
             ctl[0:1] = norm
             ctl[1:2] = torch.where(bad, torch.zeros_like(coef), coef)
             ctl[2:3] = bad.to(torch.float32)
-        a = hip.AdamArgs()
+        # per-parameter step counters (torch.optim.AdamW semantics, as optim.FusedAdam): a parameter that had no gradient
+        # in some step falls behind; the bias corrections are per launch, so entries are bucketed by their counter --
+        # one launch in the usual case
+        by_step = {}
+        for e in ent:
+            by_step.setdefault(self._pstep.get(id(e[6]), 0), []).append(e)
         b1, b2 = self.betas
-        a.beta1, a.beta2, a.eps = b1, b2, self.eps
-        if self.bias_correction:
-            a.inv_bc1, a.inv_bc2 = 1.0 / (1.0 - b1 ** self.step_count), 1.0 / (1.0 - b2 ** self.step_count)
-        else:
-            a.inv_bc1 = a.inv_bc2 = 1.0
-        a.adam_w_mode = 1 if self.adam_w_mode else 0
-        self._apply(tab, a, ctl)
+        for step0, es in sorted(by_step.items()):
+            tb = tab if len(by_step) == 1 else self._table(es)
+            n_ = tb['nt']
+            if n_:
+                lrwd = torch.tensor([self.param_groups[e[5]]['lr'] for e in es] +
+                                    [self.param_groups[e[5]]['weight_decay'] for e in es], dtype=torch.float32)
+                tb['dev_f'][:2 * n_].copy_(lrwd, non_blocking=True)
+            a = hip.AdamArgs()
+            a.beta1, a.beta2, a.eps = b1, b2, self.eps
+            if self.bias_correction:
+                a.inv_bc1, a.inv_bc2 = 1.0 / (1.0 - b1 ** (step0 + 1)), 1.0 / (1.0 - b2 ** (step0 + 1))
+            else:
+                a.inv_bc1 = a.inv_bc2 = 1.0
+            a.adam_w_mode = 1 if self.adam_w_mode else 0
+            self._apply(tb, a, ctl)
+        for pid in {id(e[6]) for e in ent}:
+            self._pstep[pid] = self._pstep.get(pid, 0) + 1
         # every rank's updated slice -> every rank's full flat parameters (in place: the slice is the rank's
         # own chunk of the output buffer)
         if red.world > 1:
-            for pt in self.parts:
-                if getattr(pt.bucket, 'shard32', None) is None:
+            for pt in self.parts:       # the same buckets on every rank: routing is static, prepare() walks the same graph
+                if getattr(pt.bucket, 'shard32', None) is None or not getattr(pt.bucket, 'has_grad', False):
                     continue
                 dist.all_gather_into_tensor(pt.pflat, pt.pflat[pt.lo:pt.hi], group=red.pg)
         # the parameters changed behind autograd's back: invalidate the engine's bf16 weight shadows
@@ -216,13 +265,17 @@ class ZeroAdam:
     # rank-local state (like DeepSpeed's zero_pp_rank_* files): moments of this rank's slices + the step counter
     def state_dict(self):
         return {'step': self.step_count,
-                'parts': [{'m': pt.m.clone(), 'v': pt.v.clone()} for pt in (self.parts or [])]}
+                'parts': [{'key': self._part_key(pt), 'm': pt.m.clone(), 'v': pt.v.clone(),
+                           'steps': [self._pstep.get(id(p), 0) for p, _, _ in pt.entries]} for pt in (self.parts or [])]}
 
     def load_state_dict(self, sd):
+        """Natural resume order works: build, load_state_dict, train.  The partition only exists once a backward has run
+        (the engine's gradient buckets are created by it), so before that the state is kept and applied, validated
+        against each bucket's identity, when the first step() builds the partition."""
         self.step_count = int(sd['step'])
-        if sd['parts']:
-            if self.parts is None:
-                self._build()
-            for pt, st in zip(self.parts, sd['parts']):
-                pt.m.copy_(st['m'])
-                pt.v.copy_(st['v'])
+        if not sd['parts']:
+            return
+        if self.parts is None:
+            self._pending_state = sd
+        else:
+            self._apply_state(sd)

@@ -265,6 +265,13 @@ def run_module_case(name, preset, B, seed=0, compact_logits=False):
     finally:
         torch.multinomial = real_multinomial
     rec = {'itm_img_neg_idx': np.array(drawn[:B]), 'itm_txt_neg_idx': np.array(drawn[B:2 * B])}
+    # the reference tokenizer's top-2 logit gap at every masked patch, aligned with ret.mim_labels
+    # (objectives.py:532-540): a visual-token id may only differ from the reference's where this gap is a near-tie
+    with torch.no_grad():
+        dl = model.d_vae.encoder(batch['image4dalle'])
+    t2 = dl.topk(2, dim=1).values
+    pos = batch['image_bool_masked_pos'].flatten(1).to(torch.bool)
+    rec['mim_label_top2_gap'] = (t2[:, 0] - t2[:, 1]).flatten(1)[pos].numpy().astype(np.float32)
     total = 0
     for k, v in ret.items():
         if torch.is_tensor(v) and compact_logits and k in ('mlm_logits', 'mim_logits'):
@@ -307,6 +314,8 @@ def main():
         'backbone_large_b2': lambda: run_backbone_case('backbone_large_b2', 'large', B=2, full_out=False, full_grad_max=1024),
         'module_mini': lambda: run_module_case('module_mini', 'mini', B=4),
         'module_base_b2': lambda: run_module_case('module_base_b2', 'base', B=2, compact_logits=True),
+        # BASELINE.json configs[4]'s model: VLMo-Large + the full objective + the in-loop dVAE tokenizer
+        'module_large_b2': lambda: run_module_case('module_large_b2', 'large', B=2, compact_logits=True),
         'dvae_tiny': lambda: run_dvae_case('dvae_tiny', B=2, res=32, n_hid=64, vocab_size=512),
         'dvae_small': lambda: run_dvae_case('dvae_small', B=2, res=32, n_hid=256, vocab_size=1024),
         'dvae_full_b2': lambda: run_dvae_case('dvae_full_b2', B=2, res=112, full_logits=False),

@@ -207,6 +207,58 @@ def _sink_edge_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _rs_accumulate_worker(rank, world, port, q):
+    """Gradient partition (reduce_scatter=True) + gradient accumulation with fp32 communication (what gloo and
+    `--comm-dtype fp32` use): the sink's flat buffer is the rank-LOCAL accumulator there, so packing must not scale it in
+    place -- after every micro-step the shard is this rank's slice of mean_r(sum of the micro-steps so far)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from exploremultimodal_amd.dp import GradReducer
+        model = Tiny()
+        red = GradReducer(model, reduce_scatter=True, engine_sink=False)
+        group = tuple(model.blocks[0]['a'].parameters())
+        n = sum(p.numel() for p in group)
+        mean = lambda f: sum(f(r) for r in range(world)) / world
+        for window in range(2):
+            tot = 0.0
+            for micro, acc in enumerate([True, True, False]):
+                x = torch.ones(3, requires_grad=True)
+                y = _FakeEngineFn.apply(x, red, [group], float((rank + 1) * (micro + 1) * (window + 1)))
+                loss = y.sum()
+                red.prepare(loss)
+                loss.backward()
+                red.finish(accumulate=acc)
+                tot += mean(lambda r: (r + 1.0) * (micro + 1) * (window + 1))
+                sb = red.sinks[red._key(group)]
+                assert sb.has_grad
+                lo = rank * (sb.padded // world)
+                valid = max(0, min(n - lo, sb.shard.numel()))
+                assert torch.allclose(sb.shard[:valid], torch.full((valid,), tot)), (window, micro, sb.shard[:3], tot)
+            for p in group:
+                p.grad = None
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_with_accumulation_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rs_accumulate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
+
+
 def test_engine_sink_dropped_pass_and_accumulation_world2_gloo():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -324,7 +376,7 @@ def _zero_worker(rank, world, port, q):
             def _views(self, tab):
                 import ctypes
                 out = []
-                for (pp, gp, mp_, vp, n, gi) in tab['ent']:
+                for (pp, gp, mp_, vp, n, gi, _p) in tab['ent']:
                     mk = lambda a: torch.frombuffer((ctypes.c_float * n).from_address(a), dtype=torch.float32)
                     out.append((mk(pp), mk(gp), mk(mp_), mk(vp), gi))
                 return out
@@ -392,6 +444,74 @@ def _zero_worker(rank, world, port, q):
         # the moments exist only for this rank's slices
         total = sum(pt.padded for pt in opt.parts)
         assert sum(pt.m.numel() for pt in opt.parts) * world == total
+
+        # A step in which NOTHING feeds the sink bucket (every pass that uses block 1 dropped from the loss): its
+        # persistent shard still holds the previous step's gradient and must not be applied again -- torch.optim skips
+        # grad=None parameters (no update, no weight decay, no moment decay), and so must the sharded step.
+        def one_step(step, feed_sink, mdl, rd, op, rmdl, rop):
+            g = torch.Generator().manual_seed(11 + rank + 10 * step)
+            x = torch.randn(6, 8, generator=g)
+            for m in (mdl, rmdl):
+                for p in m.parameters():
+                    p.grad = None
+            lin = mdl.blocks[1]['a']
+            grp = (lin.weight, lin.bias)
+            lay = [(lin.weight, 0), (lin.bias, lin.weight.numel() + 7)]
+            loss = mdl(x).square().mean()
+            rd.prepare(loss)
+            loss.backward()
+            if feed_sink:
+                flat = rd.acquire(grp, sink_n, torch.device('cpu'), layout=lay)
+                for p, off in lay:
+                    flat[off:off + p.numel()] += p.grad.reshape(-1)
+            for p in grp:
+                p.grad = None
+            if feed_sink:
+                rd.release_all([grp])
+            rd.finish()
+            op.step(clip_grad=0.5)
+            rmdl(x).square().mean().backward()
+            if not feed_sink:
+                for p in rmdl.blocks[1]['a'].parameters():
+                    p.grad = None
+            for p in rmdl.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad)
+                    p.grad /= world
+            torch.nn.utils.clip_grad_norm_([p for p in rmdl.parameters() if p.grad is not None], 0.5)
+            rop.step()
+            for (n, p), pr in zip(mdl.named_parameters(), rmdl.parameters()):
+                if 'unused' not in n:
+                    assert torch.allclose(p.detach(), pr.detach(), rtol=1e-4, atol=5e-5), (step, n, (p - pr).abs().max())
+
+        before = [p.detach().clone() for p in group]
+        one_step(3, False, model, red, opt, ref, ropt)
+        assert all(torch.equal(b_, p.detach()) for b_, p in zip(before, group)), 'a bucket without a gradient was stepped'
+        one_step(4, True, model, red, opt, ref, ropt)
+
+        # resume in the natural order: build, load_state_dict (before any backward has created the gradient buckets), train
+        sd_model = {k: v.clone() for k, v in model.state_dict().items()}
+        sd_opt = opt.state_dict()
+        assert all('key' in st for st in sd_opt['parts'])
+        red.close()
+        model2 = Tiny()
+        model2.load_state_dict(sd_model)
+        red2 = GradReducer(model2, reduce_scatter=True, engine_sink=False)
+        lin2 = model2.blocks[1]['a']
+        red2._sink_params.update(id(p) for p in (lin2.weight, lin2.bias))
+        opt2 = CpuZero(red2, groups_of(model2), betas=(0.9, 0.98), eps=1e-5)
+        opt2.load_state_dict(sd_opt)
+        assert opt2.parts is None and opt2.step_count == opt.step_count
+        one_step(5, True, model2, red2, opt2, ref, ropt)       # `ref` / `ropt` simply keep going
+        bad = dict(sd_opt)
+        bad['parts'] = list(reversed(sd_opt['parts']))
+        opt3 = CpuZero(red2, groups_of(model2), betas=(0.9, 0.98), eps=1e-5)
+        opt3.parts = opt2.parts
+        try:
+            opt3.load_state_dict(bad)
+            raise AssertionError('a permuted ZeroAdam state was accepted')
+        except ValueError:
+            pass
         q.put((rank, 'ok'))
     except Exception:  # noqa: BLE001
         import traceback

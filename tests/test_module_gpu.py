@@ -46,14 +46,19 @@ def test_build_model_contract():
         m.infer({}, infer_mode='bogus')
 
 
-@pytest.mark.parametrize('name,preset', [('module_mini', 'mini'), ('module_base_b2', 'base')])
-def test_module_forward_matches_reference(golden_dir, name, preset):
+@pytest.mark.parametrize('fused_ce', [False, True])
+@pytest.mark.parametrize('name,preset', [('module_mini', 'mini'), ('module_base_b2', 'base'), ('module_large_b2', 'large')])
+def test_module_forward_matches_reference(golden_dir, name, preset, fused_ce):
     """module_base_b2: the full objective at the VLMo-Base shape (BASELINE.json configs[4]'s compute_mim + in-loop
     dVAE tokenizer on 112x112 inputs, 8192-way visual vocabulary, tied 30522-way MLM decoder), batch 2; its
-    full-vocabulary logits are pinned by every 61st column, the row log-sum-exp and the arg-max."""
+    full-vocabulary logits are pinned by every 61st column, the row log-sum-exp and the arg-max.  module_large_b2: the
+    same at VLMo-Large (configs[4]'s model).  fused_ce: the two vocabulary heads through the HIP cross-entropy path
+    (heads.LinearCrossEntropyFn: no logits in HBM) -- losses, accuracies and every parameter gradient against the
+    same reference fixture; the logits keys are then present with value None (documented deviation)."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     B = int(g['meta.B'])
     model, cfg = _build(preset)
+    cfg.train.fused_ce = fused_ce
     batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, B, seed=1234).items()}
     batch['itm_neg_idx'] = (torch.from_numpy(g['itm_img_neg_idx']).to(DEV), torch.from_numpy(g['itm_txt_neg_idx']).to(DEV))
     ret = model(batch)
@@ -70,11 +75,25 @@ def test_module_forward_matches_reference(golden_dir, name, preset):
         rep[ln] = (got, ref)
         assert abs(got - ref) <= 2e-2 + 2e-3 * abs(ref), (ln, got, ref)
     print(rep)
+    # visual-token labels from the in-loop dVAE (objectives.py:532-540): >= 99 % equal to the reference's, and every
+    # differing one sits where the reference's own top-2 logits are a near-tie (same rule as tests/test_dvae_gpu.py)
     lab_rows = ret['mim_labels'].cpu().numpy() == g['ret.mim_labels']
     lab_ok = lab_rows.mean()
-    assert lab_ok >= 0.95, lab_ok
+    gaps = g['mim_label_top2_gap']
+    print('mim label agreement', lab_ok, 'max reference top-2 gap among mismatches', gaps[~lab_rows].max() if (~lab_rows).any() else 0)
+    assert lab_ok >= 0.99, lab_ok
+    assert (gaps[~lab_rows] < 3e-2).all()
     np.testing.assert_array_equal(ret['mlm_labels'].cpu().numpy(), g['ret.mlm_labels'])
+    for ln in ('mlm', 'mim'):
+        assert int(ret[f'{ln}_count']) == int(g[f'ret.{ln}_count'])
+        # accuracy = arg-max == label: the fused path takes the arg-max inside the GEMM epilogue
+        ref_am = g[f'ret.{ln}_logits_argmax'] if f'ret.{ln}_logits_argmax' in g.files else g[f'ret.{ln}_logits'].argmax(1)
+        ref_acc = float((ref_am == g[f'ret.{ln}_labels']).mean())
+        assert abs(float(ret[f'{ln}_mean_acc']) - ref_acc) <= 2.0 / max(1, int(g[f'ret.{ln}_count'])), (ln, float(ret[f'{ln}_mean_acc']), ref_acc)
     for k in ('mlm_logits', 'sim_i2t', 'itm_logits', 'mim_logits'):
+        if ret[k] is None:
+            assert fused_ce and k in ('mlm_logits', 'mim_logits')
+            continue
         got = ret[k].detach().float().cpu()
         if 'ret.' + k in g.files:
             err = np.abs(got.numpy() - g['ret.' + k]).max()
@@ -96,8 +115,9 @@ def test_module_forward_matches_reference(golden_dir, name, preset):
         pr = (gr.double() * grad_probe(k, gr.shape).double()).sum().item()
         rel = max(abs(gr.norm().item() - gn), abs(pr - float(g['grad_probe.' + k]))) / (gn + 1e-12)
         worst = max(worst, (rel, k))
-        # 2-layer shape: 6 %; the 12-layer Base shape at batch 2 (bf16 operands, four summed losses): 8 %
-        assert rel <= (6e-2 if cfg.model.depth <= 3 else 8e-2), (k, rel)
+        # 2-layer shape: 6 %; the 12-layer Base shape at batch 2 (bf16 operands, four summed losses): 8 %;
+        # 24-layer Large: 10 %
+        assert rel <= (6e-2 if cfg.model.depth <= 3 else (8e-2 if cfg.model.depth <= 12 else 1e-1)), (k, rel)
     print('worst grad', worst)
 
 

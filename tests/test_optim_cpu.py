@@ -69,15 +69,6 @@ def test_factory_dispatch():
         o.step()
 
 
-def test_cosine_scheduler_table():
-    s = optim.cosine_scheduler(2e-4, 1e-6, epochs=3, niter_per_ep=10, warmup_epochs=1, start_warmup_value=0.0)
-    assert len(s) == 30 and s[0] == 0.0 and s[9] == pytest.approx(2e-4) and s[10] == pytest.approx(2e-4)
-    assert s[-1] == pytest.approx(1e-6 + 0.5 * (2e-4 - 1e-6) * (1 + math.cos(math.pi * 19 / 20)))
-    assert np.all(np.diff(s[10:]) < 0)
-    s2 = optim.cosine_scheduler(1.0, 0.0, epochs=2, niter_per_ep=5, warmup_epochs=1, warmup_steps=3)
-    assert len(s2) == 10 and list(s2[:3]) == [0.0, 0.5, 1.0]
-
-
 @pytest.mark.parametrize('adam_w', [True, False])
 def test_oracle_matches_torch_adam_on_cpu(adam_w):
     g = torch.Generator().manual_seed(0)

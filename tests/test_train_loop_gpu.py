@@ -86,7 +86,7 @@ def test_synthetic_pretraining_loop_learns_and_resumes(tmp_path, with_reducer):
 
 def _run_loop(tmp_path, cfg, model, opt, reducer):
     loader = DataLoaderX(0, max_prefetch=2, dataset=_Synthetic(cfg.model, 8), batch_size=4, shuffle=False)
-    sched = _Sched(opt, optim.cosine_scheduler(1.0, 0.1, epochs=4, niter_per_ep=2, warmup_epochs=1))
+    sched = _Sched(opt, [0.0, 1.0, 1.0, 0.94, 0.775, 0.55, 0.325, 0.16])   # the caller's per-iteration lr table (warm-up + half cosine)
     scaler = optim.NativeScalerWithGradNormCount(reducer)
     losses = []
     for epoch in range(3):
@@ -164,6 +164,7 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
             torch.cuda.synchronize()
             results.append({n: p.detach().clone() for n, p in model.named_parameters()})
             red.close()
+        n_end = n_bad = 0
         for n in results[0]:
             a, b, w0 = results[0][n], results[1][n], inits[n]
             # the two runs' gradients differ by fp32 summation order (atomics in the weight-gradient / column-sum /
@@ -171,6 +172,16 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
             # so the comparison is on the UPDATE as a whole: the two runs' updates agree to 3 % of their norm
             upd = (b - w0).norm().item()
             assert (a - b).norm().item() <= 3e-2 * upd + 1e-7, (n, (a - b).norm().item(), upd)
+            # 3 % of a norm would hide a handful of wrong elements, which is what a mis-cut slice leaves behind (the
+            # first / last elements of a parameter's overlap with the rank's slice stepped with a neighbour's gradient,
+            # or not stepped at all: an error of the size of the whole per-element update).  So, element by element at
+            # both ends of every parameter: within a third of the update's RMS, allowing the rare near-zero-gradient
+            # element whose Adam update flips with the summation order.
+            rms = upd / max(1.0, a.numel()) ** 0.5
+            ends = torch.cat([(a - b).flatten()[:8], (a - b).flatten()[-8:]]).abs()
+            n_end += ends.numel()
+            n_bad += int((ends > rms / 3 + 1e-9).sum())
+        assert n_bad <= 0.02 * n_end, (n_bad, n_end)
     finally:
         for r in reds:
             r.close()
