@@ -17,6 +17,8 @@
 // [M, 3d] qkv matrix, so text+image fusion needs no concatenated copy.
 #include "common.h"
 #include "vlmo_hip.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -30,7 +32,7 @@ struct AttnArgs {
     const int32_t* keymask;
     int lse_stride, heads, d;
     float scale, scale_log2e;
-    uint32_t drop_thresh;
+    uint32_t drop_thresh, drop_cmp;     // drop_cmp = thresh << 16: keep <=> att_mix(...) >= drop_cmp
     float inv_keep;
     uint64_t seed;
 };
@@ -56,20 +58,20 @@ __device__ __forceinline__ void stage_image(const bf16* base, int ld, int col0, 
 }
 
 // ---- attention dropout (vlmo.py:93): counter-based, regenerated in the backward -------------------------------
-// keep(seq*heads + head, q, key) <=> u16 >= thresh with u16 = half (key & 1) of att_mix(c * G + att_key),
-// c = q * 512 + (key >> 1).  One multiply round (the probabilities are ~26 VALU instructions per score element in
-// these kernels and VALU issue is what bounds them: the two-round hash32 + 64-bit counter cost 17 of them in the
-// dK/dV phase); a lane owning a query gets two keys per hash, a lane owning a key one element per hash, and the
-// counter is affine in both q and key so either orientation advances it with ONE add of a compile-time constant.
+// keep(seq*heads + head, q, key) <=> top 16 bits of att_mix(c * G + att_key) >= thresh, c = q * 512 + key (sequences
+// are < 512 tokens).  The soft-max arithmetic of these kernels is bound by VALU ISSUE (one wave alone on a SIMD issues
+// a vector instruction every 4 cycles; the single-pass backward spends ~2/3 of a step in it), so the hash is as short
+// as its use allows: the counter is affine in q and in key (either orientation advances it with ONE add of a
+// compile-time constant), one xor-shift + one multiply mix it, and only the TOP half of the product is used -- the
+// best-mixed bits, compared as a whole word against thresh << 16 (no field extraction).  5 instructions per element.
 #define ATT_G 0x9E3779B1u
 #define ATT_G512 ((uint32_t)(512ull * ATT_G))
 __device__ __forceinline__ uint32_t att_key(uint64_t seed, int bh) {
     return hash32((uint32_t)seed ^ ((uint32_t)bh * 0x9E3779B9u)) + (uint32_t)(seed >> 32);
 }
 __device__ __forceinline__ uint32_t att_mix(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7feb352du;
     x ^= x >> 15;
+    x *= 0x7feb352du;
     return x;
 }
 
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
     for (int qt = wave; qt < nq; qt += 4) {
         const int qi = qt * 32 + l31;
         const int qrow = rowidx[qi];
-        const uint32_t rq = ((uint32_t)qi * 512u + 2u * h) * ATT_G + akey;     // dropout counter base of this lane
+        const uint32_t rq = ((uint32_t)qi * 512u + 4u * h) * ATT_G + akey;     // dropout counter base of this lane
         const bf16* qp = a.qkv + (size_t)qrow * ld + hd * 64 + 8 * h;
         bf16x8 qf[4];
 #pragma unroll
@@ -194,15 +196,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
                 const int kt = c0 + c;
                 if (kt < nq) {
                     if (a.drop_thresh) {
-                        const uint32_t rk = rq + (uint32_t)(kt * 16) * ATT_G;
+                        const uint32_t rk = rq + (uint32_t)(kt * 32) * ATT_G;
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                            for (int jj = 0; jj < 2; ++jj) {
-                                const uint32_t r = att_mix(rk + (uint32_t)(4 * g4 + jj) * ATT_G);
-                                if ((r & 0xFFFFu) < a.drop_thresh) S[c][4 * g4 + 2 * jj] = 0.f;
-                                if ((r >> 16) < a.drop_thresh) S[c][4 * g4 + 2 * jj + 1] = 0.f;
-                            }
+                            for (int e = 0; e < 4; ++e)
+                                if (att_mix(rk + (uint32_t)(8 * g4 + e) * ATT_G) < a.drop_cmp) S[c][4 * g4 + e] = 0.f;
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             df[s] = row_frag(Dimg, qt * 32, s, lane);
         }
         const float lq = lseq[qi], dl = delta[qi];
-        const uint32_t rq = ((uint32_t)qi * 512u + 2u * h) * ATT_G + akey;
+        const uint32_t rq = ((uint32_t)qi * 512u + 4u * h) * ATT_G + akey;
         f32x16 dQ[2] = {zero16(), zero16()};
         for (int kt = 0; kt < nq; ++kt) {
             {
@@ -318,22 +317,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                     S = Elem<bf16>::mfma(row_frag(Kimg, kt * 32, s, lane), qf[s], S);
                     dP = Elem<bf16>::mfma(row_frag(Vimg, kt * 32, s, lane), df[s], dP);
                 }
-                const uint32_t rk = rq + (uint32_t)(kt * 16) * ATT_G;
+                const uint32_t rk = rq + (uint32_t)(kt * 32) * ATT_G;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 kb = *(const f32x4*)(kbias + kt * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        uint32_t r = 0xFFFFFFFFu;
-                        if (a.drop_thresh) r = att_mix(rk + (uint32_t)(4 * g4 + jj) * ATT_G);
-#pragma unroll
-                        for (int e2 = 0; e2 < 2; ++e2) {
-                            const int e = 2 * jj + e2, i = 4 * g4 + e;
-                            const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + (kb[e] - lq));
-                            const bool keep = (e2 ? (r >> 16) : (r & 0xFFFFu)) >= a.drop_thresh;
-                            const float dp = keep ? dP[i] : 0.f;
-                            S[i] = p * (dp - dl);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g4 + e;
+                        const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + (kb[e] - lq));
+                        bool keep = true;
+                        if (a.drop_thresh) keep = att_mix(rk + (uint32_t)(8 * g4 + e) * ATT_G) >= a.drop_cmp;
+                        const float dp = keep ? dP[i] : 0.f;
+                        S[i] = p * (dp - dl);
                     }
                 }
 #pragma unroll
@@ -371,10 +366,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             vf[s] = row_frag(Vimg, kt * 32, s, lane);
         }
         const float kb = kbias[ki];
-        // dropout counter of (q, ki) = q * 512 + (ki >> 1): affine in q, so a lane walks its 16 queries of a tile
-        // with compile-time constant adds; its element is the (ki & 1) half of the hash
-        const uint32_t rl = (uint32_t)(ki >> 1) * ATT_G + akey + (uint32_t)(4 * h) * ATT_G512;
-        const uint32_t rsh = 16u * (ki & 1);
+        // dropout counter of (q, ki) = q * 512 + ki: affine in q, so a lane walks its 16 queries of a tile with
+        // compile-time constant adds
+        const uint32_t rl = (uint32_t)ki * ATT_G + akey + (uint32_t)(4 * h) * ATT_G512;
         f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};
         for (int qt = 0; qt < nq; ++qt) {
             {
@@ -396,8 +390,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                         const int i = 4 * g4 + e;
                         const float p = __builtin_amdgcn_exp2f(S[i] * a.scale_log2e + (kb - lq[e]));
                         bool keep = true;
-                        if (a.drop_thresh)
-                            keep = __builtin_amdgcn_ubfe(att_mix(rqt + (uint32_t)(8 * g4 + e) * ATT_G512), rsh, 16u) >= a.drop_thresh;
+                        if (a.drop_thresh) keep = att_mix(rqt + (uint32_t)(8 * g4 + e) * ATT_G512) >= a.drop_cmp;
                         Pd[i] = keep ? p : 0.f;
                         S[i] = p * ((keep ? dP[i] : 0.f) - dl[e]);
                     }
@@ -436,9 +429,331 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     }
 }
 
+// ------------------------------------------------------------------ backward, single pass
+// One workgroup = one (sequence, head); wave w OWNS key tile w (32 keys: its K / V row fragments, dK^T and dV^T
+// accumulators) AND the dQ^T accumulators of query tile w.  The nq x nq tile pairs are swept along the diagonals of a
+// rotation: in step t wave w works on (query tile (w + t) mod nq, key tile w), so S, dP, P and dS of every pair are
+// computed exactly ONCE (the two-phase kernel above computes them in the dK/dV items and again in the dQ items: 28
+// MFMAs and two passes of soft-max / dropout arithmetic per pair instead of 20 and one).  With the key on the lane
+// (S = Q . K^T, rows = queries) the accumulator tiles P and dS are directly the B operands of dV^T += dO^T . P and
+// dK^T += Q^T . dS; only dS crosses LDS, once: the wave stores its bf16 tile [key][query] into its slot and, after the
+// step's barrier, the owner of that query tile reads it back transposed (ds_read_b64_tr_b16) as the B operand of
+// dQ^T += K^T . dS^T.  Slots are double buffered: one barrier per step.
+// Row constants ride in as INITIAL accumulators: S starts at -lse / scale and dP at -delta, so p = exp2(c * S' + keybias)
+// and dS = p * dP' need no per-element subtraction (cdna guide, attention backward).
+// LDS at 256 padded tokens (8 key tiles): Q, dO, K images 3 x 32 KB + 2 x 8 slots of 2 KB + row constants = 132 KB.
+__device__ __forceinline__ int slot_off(int k, int q) {
+    // [key][query] bf16 tile, 64-byte rows, 8-byte units XOR-swizzled by the key pair: conflict-free for the producer's
+    // ds_write_b64 (16 consecutive keys, one unit) and for the consumer's transposed reads (4 keys x 8 units)
+    return k * 64 + ((((q >> 2) ^ (k >> 1)) & 7) << 3) + (q & 3) * 2;
+}
+// One wave per key tile, at most 8 (two per SIMD, 251 registers): a ninth wave would put three on one SIMD, i.e. a
+// 168-register budget against 96 accumulator registers + V fragments + the S / dP tiles -- hipcc spills 160-330
+// registers there and the N = 261 backward takes 200-450 us instead of 120.  Sequences of 257-288 tokens (the fused
+// layers at T = 64) therefore stay on the two-phase kernel above.
+// Measured (MI355X, B = 64, 12 heads, dropout 0.1; tools/attn_bench.py): N = 197 81 us (two-phase 94), N = 64 16 us (25).
+// Per workgroup at N = 197 (s_memrealtime stamps): 7 us before the first product (165 KB through one CU's vector
+// memory path at ~25 GB/s: images + V fragments + the ctx / dctx rows for delta), 13 us in the loop (1.9 us per step:
+// the two waves of a SIMD spend it in ~180 + ~180 soft-max / dropout instructions, SQ_ACTIVE_INST_VALU is what bounds
+// it, the 40 MFMAs of both hide under it), 2-3 us of stores; one workgroup per CU, so the three phases add.
+__global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const int NPAD) {
+    constexpr bool KF_REG = false;      // K row fragments re-read from the LDS image each step (16 registers: no spill)
+    const int IMG = NPAD * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qimg = smem;
+    char* Dimg = smem + IMG;
+    char* Kimg = smem + 2 * IMG;
+    const int nt = NPAD >> 5;
+    char* slots = smem + 3 * IMG;                           // [2][nt][2048]
+    float* kbias = (float*)(slots + 2 * nt * 2048);
+    float* nlq = kbias + NPAD;      // -lse / scale per query (-inf on padded queries)
+    float* ndl = nlq + NPAD;        // -delta * keep_prob
+
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int bh = blockIdx.x, sidx = bh / a.heads, hd = bh % a.heads;
+    const int ld = 3 * a.d;
+    // Prologue with ONE level of dependent loads: the packed row of a token is arithmetic on the sequence's four
+    // descriptor words (scalar loads), so the LDS-DMA of the three images, the key mask, the rows of ctx / dctx for
+    // delta, the log-sum-exp and this wave's V fragments are all issued together (a row table in LDS first costs two more
+    // global round trips and a barrier: 6.4 of the 7.2 us a workgroup spent before its first product).
+    const int rowA = a.seg[4 * sidx + 0], lenA = a.seg[4 * sidx + 1], rowB = a.seg[4 * sidx + 2], lenB = a.seg[4 * sidx + 3];
+    const int N = lenA + lenB;
+    auto rowof = [&](int tok) {
+        tok = min(tok, N - 1);
+        return tok < lenA ? rowA + tok : rowB + (tok - lenA);
+    };
+    const int nq = (N + 31) >> 5;
+    for (int ii = w; ii < nq * 4; ii += nw) {
+        const int chhi = lane >> 5, rowlo = (lane >> 2) & 7, pc = lane & 3;
+        const int row = ii * 8 + rowlo;
+        const int ch = chhi * 4 + (pc ^ ((row >> 2) & 3));
+        const size_t r = (size_t)rowof(row);
+        glds16(a.qkv + r * ld + hd * 64 + ch * 8, Qimg + ii * 1024);
+        glds16(a.qkv + r * ld + a.d + hd * 64 + ch * 8, Kimg + ii * 1024);
+        glds16(a.dctx + r * a.d + hd * 64 + ch * 8, Dimg + ii * 1024);
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool active = w < nq;
+    const int ki = w * 32 + l31;
+    const int krow = rowof(ki);
+    // row fragments (B operands) of this wave's keys straight from global memory: V has no LDS image at all
+    bf16x8 kf[4], vf[4];
+    if (active) {
+        const bf16* kp = a.qkv + (size_t)krow * ld + a.d + hd * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (KF_REG) kf[s] = *(const bf16x8*)(kp + 16 * s);
+            vf[s] = *(const bf16x8*)(kp + a.d + 16 * s);
+        }
+    }
+    const float keep_prob = 1.f / a.inv_keep;
+    const float inv_scale = 1.f / a.scale;
+    for (int i = threadIdx.x; i < NPAD; i += blockDim.x) {
+        float dl = 0.f, lq = INFINITY;
+        const int row = rowof(i);
+        const bool ok = (i < N) && (!a.keymask || a.keymask[row] != 0);
+        if (i < N) {
+            const size_t o = (size_t)row * a.d + hd * 64;
+            bf16x8 x[8], y[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                x[c] = *(const bf16x8*)(a.ctx + o + 8 * c);
+                y[c] = *(const bf16x8*)(a.dctx + o + 8 * c);
+            }
+            lq = a.lse[(size_t)bh * a.lse_stride + i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)x[c][j] * (float)y[c][j];
+        }
+        kbias[i] = ok ? 0.f : -INFINITY;
+        ndl[i] = -dl * keep_prob;       // dS = scale * inv_keep * P * (keep * dP - delta * keep_prob)
+        nlq[i] = -lq * inv_scale;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const uint32_t akey = att_key(a.seed, bh);
+    const float out_scale = a.scale * a.inv_keep;
+    const float c_l2 = a.scale_log2e;
+    const float kb = kbias[min(ki, NPAD - 1)];
+    // dropout counter of (q, ki) = q * 512 + ki: affine in q (see attn_bwd_kernel)
+    const uint32_t rl = (uint32_t)ki * ATT_G + akey + (uint32_t)(4 * h) * ATT_G512;
+    f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()}, dQ[2] = {zero16(), zero16()};
+
+    // LDS addressing with FOUR per-lane offsets for all image accesses (att_off spelled out for tile-aligned bases: the
+    // row base enters as 128 * row (a scalar), the k-step / feature half as immediates), so that the loop does not
+    // carry ~50 address registers:
+    //   row fragment (rows rb + l31, 16-byte chunk 2 s + h):   img + 128 rb + 512 (s >> 1) + rf[s & 1]
+    //   transposed fragment (rows rb + ..., features cb + ...): img + 128 rb + 512 (cb >> 5) + {trl | trh}
+    const int xq = (l31 >> 2) & 3;
+    const int rf0 = 1024 * (l31 >> 3) + 64 * (l31 & 7) + 16 * (h ^ xq);
+    const int rf1 = 1024 * (l31 >> 3) + 64 * (l31 & 7) + 16 * ((2 + h) ^ xq);
+    const int tg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int trl = 64 * (4 * h + tq) + 16 * ((2 * tg + (tp >> 1)) ^ h) + 8 * (tp & 1);
+    const int trh = 1024 + 64 * (4 * h + tq) + 16 * ((2 * tg + (tp >> 1)) ^ ((2 + h) & 3)) + 8 * (tp & 1);
+    auto rfrag = [&](const char* img_rb, int s) -> bf16x8 {     // img_rb = image + 128 * row base (wave-uniform)
+        return *(const bf16x8*)(img_rb + 512 * (s >> 1) + ((s & 1) ? rf1 : rf0));
+    };
+    auto tfrag = [&](const char* img_rb, int dt) -> bf16x8 {    // img_rb = image + 128 * (row base of the 16-row k-step)
+        const bf16x4 lo = lds_tr4<bf16>(img_rb + 512 * dt + trl);
+        const bf16x4 hi = lds_tr4<bf16>(img_rb + 512 * dt + trh);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    // slot tile [key][query] (slot_off): the producer's two 8-byte stores per k-step, the consumer's transposed reads
+    const int sw0 = slot_off(l31, 4 * h), sw1 = slot_off(l31, 8 + 4 * h);           // k-step 1: + 32 bytes XOR-wise
+    const int srl = slot_off(4 * h + tq, 16 * tg + 4 * tp), srh = slot_off(8 + 4 * h + tq, 16 * tg + 4 * tp);
+    auto sfrag = [&](const char* slot, int s2) -> bf16x8 {
+        const bf16x4 lo = lds_tr4<bf16>(slot + 1024 * s2 + srl);
+        const bf16x4 hi = lds_tr4<bf16>(slot + 1024 * s2 + srh);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    // One step of a wave = four stages:
+    //   sdp   S = Q K^T - lse / scale, dP = dO V^T                      8 MFMAs   (row fragments of Q, dO)
+    //   valu  p = exp2(c S + keybias), dropout, dS = p (dP - delta)      ~15 VALU instructions per element; dS -> slot
+    //   dvdk  dV^T += dO^T P, dK^T += Q^T dS                             8 MFMAs   (transposed fragments of dO, Q)
+    //   dq    dQ^T += K^T dS^T for the query tile this wave owns         4 MFMAs   (behind the step's barrier)
+    // Left alone, the compiler issues every LDS read right in front of the MFMA that uses it (the LDS latency is then
+    // exposed 20 times per step): operands are fetched a stage ahead and __builtin_amdgcn_sched_barrier(0) keeps the
+    // fetch groups where they are written.
+    // The two waves of a SIMD (w and w + 4) run the stages in DIFFERENT orders between two barriers, so that one is in
+    // its MFMA stages while the other does arithmetic (in lockstep every SIMD alternates between idle matrix pipe and
+    // idle vector issue, and all waves queue on the LDS port together):
+    //   w <  4:  | dq(t-1) sdp(t) valu(t) dvdk(t)          | barrier t
+    //   w >= 4:  | valu(t) dvdk(t) dq(t-1) sdp(t+1)        | barrier t        (sdp(0) in front of the loop)
+    // Legal because dq(t-1) only needs barrier t-1 behind it and the slot buffer it reads is rewritten after barrier t.
+    bf16x8 qa[4], da[4], pf[2], sf[2];
+    f32x16 S, dP;
+    auto fetch_a = [&](int qt_) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qa[s] = rfrag(Qimg + qt_ * 4096, s);
+            da[s] = rfrag(Dimg + qt_ * 4096, s);
+        }
+    };
+    auto qtile = [&](int t_) {
+        int q_ = w + t_;
+        return q_ >= nq ? q_ - nq : q_;
+    };
+    auto stage_sdp = [&](int qt) {      // qa / da hold the fragments of query tile qt
+        // the row constant -lse / scale as the initial accumulator of S (dP starts at zero: its row constant -delta
+        // is needed as a value by the dropout select anyway, and a second set of initial registers spills)
+        dP = zero16();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 l4 = *(const f32x4*)(nlq + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[4 * g4 + e] = l4[e];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 kfs = KF_REG ? kf[s] : rfrag(Kimg + w * 4096, s);
+            S = Elem<bf16>::mfma(qa[s], kfs, S);
+            dP = Elem<bf16>::mfma(da[s], vf[s], dP);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_valu_dvdk = [&](int qt, int t) {
+        bf16x8 dtr[2], qtr[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dtr[dt] = tfrag(Dimg + qt * 4096, dt);
+            qtr[dt] = tfrag(Qimg + qt * 4096, dt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // P (after dropout) and dS are packed to bf16 as they are produced: registers 8 s2 .. 8 s2 + 7 of a tile are
+        // the fragment of k-step s2 of the products that follow
+        if (a.drop_thresh) {
+            const uint32_t rqt = rl + (uint32_t)(qt * 32) * ATT_G512;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 nd = *(const f32x4*)(ndl + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g4 + e;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c_l2, kb));
+                    const bool keep = att_mix(rqt + (uint32_t)(8 * g4 + e) * ATT_G512) >= a.drop_cmp;
+                    const float pd = keep ? p : 0.f;
+                    pf[i >> 3][i & 7] = (bf16)pd;
+                    sf[i >> 3][i & 7] = (bf16)fmaf(pd, dP[i], p * nd[e]);      // p * (keep * dP - delta)
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 nd = *(const f32x4*)(ndl + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g4 + e;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c_l2, kb));
+                    pf[i >> 3][i & 7] = (bf16)p;
+                    sf[i >> 3][i & 7] = (bf16)(p * (dP[i] + nd[e]));
+                }
+            }
+        }
+        char* myslot = slots + ((t & 1) * nt + w) * 2048;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            // dS^T tile for the owner of this query tile: registers 4g .. 4g+3 = queries 8g + 4h .. +3 of key l31
+            *(bf16x4*)(myslot + (sw0 ^ (32 * s2))) = bf16x4{sf[s2][0], sf[s2][1], sf[s2][2], sf[s2][3]};
+            *(bf16x4*)(myslot + (sw1 ^ (32 * s2))) = bf16x4{sf[s2][4], sf[s2][5], sf[s2][6], sf[s2][7]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the second k-step's fragments are fetched under the first one's products
+        bf16x8 dtr1[2], qtr1[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dtr1[dt] = tfrag(Dimg + qt * 4096 + 2048, dt);
+            qtr1[dt] = tfrag(Qimg + qt * 4096 + 2048, dt);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dV[dt] = Elem<bf16>::mfma(dtr[dt], pf[0], dV[dt]);
+            dK[dt] = Elem<bf16>::mfma(qtr[dt], sf[0], dK[dt]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dV[dt] = Elem<bf16>::mfma(dtr1[dt], pf[1], dV[dt]);
+            dK[dt] = Elem<bf16>::mfma(qtr1[dt], sf[1], dK[dt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // dq(t): the wave that worked on query tile w in step t owns key tile wp = (w - t) mod nq.  next_q >= 0: also fetch
+    // the row fragments of that query tile (the following sdp stage) under these products
+    auto stage_dq = [&](int t, int next_q) {
+        int wp = w - t;
+        if (wp < 0) wp += nq;
+        const char* slot = slots + ((t & 1) * nt + wp) * 2048;
+        bf16x8 ktr[2][2], sb[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            sb[s2] = sfrag(slot, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) ktr[s2][dt] = tfrag(Kimg + wp * 4096 + 2048 * s2, dt);
+        }
+        if (next_q >= 0) fetch_a(next_q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dQ[dt] = Elem<bf16>::mfma(ktr[s2][dt], sb[s2], dQ[dt]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // VALU issue is arbitrated by priority, then age: left alone the younger wave of a SIMD (w >= 4) gets the leftovers of
+    // the older one's arithmetic stage and every barrier waits for it (interval 3 900 -> 3 540 cycles with this)
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+    if (!active) {
+        for (int t = 0; t < nq; ++t) __syncthreads();
+    } else if (w < 4) {
+        fetch_a(w);
+        for (int t = 0; t < nq; ++t) {
+            const int qt = qtile(t);
+            stage_sdp(qt);
+            stage_valu_dvdk(qt, t);
+            __syncthreads();
+            stage_dq(t, t + 1 < nq ? qtile(t + 1) : -1);
+        }
+    } else {
+        fetch_a(w);
+        stage_sdp(w);
+        for (int t = 0; t < nq; ++t) {
+            stage_valu_dvdk(qtile(t), t);
+            if (t > 0) stage_dq(t - 1, -1);
+            if (t + 1 < nq) {
+                fetch_a(qtile(t + 1));
+                stage_sdp(qtile(t + 1));
+            }
+            __syncthreads();
+        }
+        stage_dq(nq - 1, -1);
+    }
+    if (active && ki < N) {
+        // ki doubles as the query index of the dQ tile this wave owns
+        bf16* op = a.out + (size_t)krow * ld + hd * 64 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 oq = {(bf16)(dQ[dt][4 * g4 + 0] * out_scale), (bf16)(dQ[dt][4 * g4 + 1] * out_scale),
+                             (bf16)(dQ[dt][4 * g4 + 2] * out_scale), (bf16)(dQ[dt][4 * g4 + 3] * out_scale)};
+                bf16x4 ok = {(bf16)(dK[dt][4 * g4 + 0] * out_scale), (bf16)(dK[dt][4 * g4 + 1] * out_scale),
+                             (bf16)(dK[dt][4 * g4 + 2] * out_scale), (bf16)(dK[dt][4 * g4 + 3] * out_scale)};
+                bf16x4 ov = {(bf16)(dV[dt][4 * g4 + 0] * a.inv_keep), (bf16)(dV[dt][4 * g4 + 1] * a.inv_keep),
+                             (bf16)(dV[dt][4 * g4 + 2] * a.inv_keep), (bf16)(dV[dt][4 * g4 + 3] * a.inv_keep)};
+                *(bf16x4*)(op + dt * 32 + 8 * g4) = oq;
+                *(bf16x4*)(op + a.d + dt * 32 + 8 * g4) = ok;
+                *(bf16x4*)(op + 2 * a.d + dt * 32 + 8 * g4) = ov;
+            }
+    }
+}
+
 // dynamic-LDS limit already raised for a kernel on a device (a process may drive several GPUs)
 int& lds_limit_set(int which) {
-    static int lim[2][64];
+    static int lim[4][64];
     static bool init = false;
     if (!init) {
         for (auto& r : lim)
@@ -471,6 +786,17 @@ int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     return 0;
 }
 
+int launch_bwd1(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
+    const int LDS = nt * 32 * 384 + 2 * nt * 2048 + nt * 32 * 16;
+    int& max_set = lds_limit_set(2);
+    if (LDS > max_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        max_set = LDS;
+    }
+    hipLaunchKernelGGL(attn_bwd1_kernel, dim3(nblocks), dim3(nt * 64), LDS, st, a, nt * 32);
+    return 0;
+}
+
 int check_common(const char* fn, const void* qkv, const int32_t* seg, int num_seq, int heads, int d, int max_len,
                  int cap) {
     VLMO_CHECK_ARG(qkv && seg, "%s: null pointer", fn);
@@ -500,6 +826,7 @@ extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, c
     a.scale = scale;
     a.scale_log2e = scale * LOG2E;
     a.drop_thresh = drop_thresh;
+    a.drop_cmp = drop_thresh >= 65536u ? 0xFFFFFFFFu : drop_thresh << 16;
     a.inv_keep = drop_thresh ? inv_keep : 1.f;
     a.seed = seed;
     const int nt = (max_len + 31) / 32, nb = num_seq * heads;
@@ -529,10 +856,15 @@ extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx,
     a.scale = scale;
     a.scale_log2e = scale * LOG2E;
     a.drop_thresh = drop_thresh;
+    a.drop_cmp = drop_thresh >= 65536u ? 0xFFFFFFFFu : drop_thresh << 16;
     a.inv_keep = drop_thresh ? inv_keep : 1.f;
     a.seed = seed;
     const int nt = (max_len + 31) / 32, nb = num_seq * heads;
-    launch_bwd(a, nt, nb, stream);
+    static const bool two_phase = getenv("VLMO_ATTN_BWD") && !strcmp(getenv("VLMO_ATTN_BWD"), "two_phase");   // measurement aid
+    if (two_phase || nt > 8)
+        launch_bwd(a, nt, nb, stream);
+    else
+        launch_bwd1(a, nt, nb, stream);
     VLMO_CHECK_LAUNCH("vlmo_attn_bwd");
     return 0;
 }

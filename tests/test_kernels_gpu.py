@@ -257,19 +257,17 @@ def _hash32(x):
 
 def _attn_keep_mask(seed, nseq, heads, N, thresh):
     """[nseq, heads, N(q), N(key)] bool: the keep mask of the attention kernels' counter-based dropout
-    (csrc/attention.hip att_key / att_mix): u16 = half (key & 1) of mix((q * 512 + (key >> 1)) * G + key(seed, bh))."""
+    (csrc/attention.hip att_key / att_mix): top 16 bits of mix((q * 512 + key) * G + key(seed, bh)) >= thresh."""
     m = np.uint64(0xFFFFFFFF)
     bh = (np.arange(nseq, dtype=np.uint64)[:, None] * np.uint64(heads) + np.arange(heads, dtype=np.uint64)[None, :])
     lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
     akey = (_hash32((lo ^ ((bh * np.uint64(0x9E3779B9)) & m)) & m) + hi) & m
     q = np.arange(N, dtype=np.uint64)[None, None, :, None]
     key = np.arange(N, dtype=np.uint64)[None, None, None, :]
-    x = ((((q * np.uint64(512) + (key >> np.uint64(1))) & m) * np.uint64(0x9E3779B1)) + akey[:, :, None, None]) & m
-    x = x ^ (x >> np.uint64(16))
-    x = (x * np.uint64(0x7feb352d)) & m
+    x = ((((q * np.uint64(512) + key) & m) * np.uint64(0x9E3779B1)) + akey[:, :, None, None]) & m
     x = x ^ (x >> np.uint64(15))
-    field = (x >> (np.uint64(16) * (key & np.uint64(1)))) & np.uint64(0xFFFF)
-    return torch.from_numpy(field >= np.uint64(thresh))
+    x = (x * np.uint64(0x7feb352d)) & m
+    return torch.from_numpy((x >> np.uint64(16)) >= np.uint64(thresh))
 
 
 def _attn_ref(qkv, seg, keymask, heads, d, dctx=None, keep=None, inv_keep=1.0):
@@ -313,6 +311,31 @@ def test_attention_fwd_bwd(B, lenA, lenB, heads):
     hip.attn_bwd(qkv, ctx, dctx, lse.view(B * heads, -1), seg, B, keymask, dqkv, heads, d, N, 64 ** -0.5)
     scale = ref_dqkv.abs().max().item()
     _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * scale, 'attn dqkv')
+
+
+def test_attention_mixed_lengths_in_one_launch():
+    """Below the fusion layer the image and the text sequences of a batch go into ONE launch (engine.Plan.seg_sep:
+    longest first): the workgroups are sized for the longest sequence and a short one uses the first waves only."""
+    B, T, P, heads = 3, 24, 197, 2
+    d = heads * 64
+    M = B * (T + P)
+    qkv = _rand(M, 3 * d, seed=5, scale=1.0)
+    seg = torch.tensor([[B * T + b * P, P, 0, 0] for b in range(B)] + [[b * T, T, 0, 0] for b in range(B)], dtype=torch.int32).to(DEV)
+    keymask = torch.ones(M, dtype=torch.int32)
+    keymask[T + 9:2 * T] = 0
+    keymask = keymask.to(DEV)
+    for drop, seed in ((None, 0), (hip.drop_params(0.1, True), 0x5EED5EED1)):
+        ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros(2 * B * heads, 224, device=DEV)
+        kw = dict(drop=drop, seed=seed) if drop else {}
+        hip.attn_fwd(qkv, seg, 2 * B, keymask, ctx, lse, heads, d, P, 64 ** -0.5, **kw)
+        keep = _attn_keep_mask(seed, 2 * B, heads, P, drop[0]) if drop else None
+        dctx = _rand(M, d, seed=79)
+        ref_ctx, ref_dqkv = _attn_ref(qkv, seg, keymask, heads, d, dctx, keep=keep, inv_keep=drop[1] if drop else 1.0)
+        _close(ctx, ref_ctx, 1 / 64, 1e-2, 'attn ctx (mixed)')
+        dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
+        hip.attn_bwd(qkv, ctx, dctx, lse, seg, 2 * B, keymask, dqkv, heads, d, P, 64 ** -0.5, **kw)
+        _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * ref_dqkv.abs().max().item(), 'attn dqkv (mixed)')
 
 
 @pytest.mark.parametrize('B,lenA,lenB,heads', [(2, 64, 197, 2), (3, 16, 17, 1)])
