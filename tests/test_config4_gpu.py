@@ -51,7 +51,7 @@ def test_large_full_objective_zero2_step():
                     p.grad = None
                 ret = model(dict(batch))
                 assert ret['mlm_logits'] is None and ret['mim_logits'] is None      # fused CE: no logits in HBM
-                assert ret['mim_labels'].numel() == B * 75                             # 75 masked patches per image
+                assert 0 < ret['mim_labels'].numel() <= B * 75                         # up to 75 masked patches per image (config.yaml:28-30)
                 parts = {k: float(v) for k, v in ret.items() if 'task_loss' in k}
                 assert all(torch.isfinite(torch.tensor(v)) for v in parts.values()), parts
                 loss = sum(v for k, v in ret.items() if 'task_loss' in k)

