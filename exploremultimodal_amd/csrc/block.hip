@@ -259,6 +259,7 @@ struct Deferred {
     std::vector<VlmoTnProblem> tn;
     std::vector<VlmoColJob> col;
     std::vector<int> blocks;
+    bool store = false;         // weight-gradient matrices are written, not accumulated (VlmoStackDesc.wgrad_store)
 };
 
 void push_fold(Deferred& D, const PartialReduce& r) {
@@ -285,7 +286,7 @@ void push_colsum(Deferred& D, const void* x, int ld, int rows, int ncols, float*
     D.col.push_back(j);
 }
 void push_tn(Deferred& D, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2) {
-    D.tn.push_back(VlmoTnProblem{A, B, C, lda, ldb, ldc, M, N1, N2, 1.f, 1});
+    D.tn.push_back(VlmoTnProblem{A, B, C, lda, ldb, ldc, M, N1, N2, 1.f, D.store ? 0 : 1});
 }
 
 // activation-gradient chain of one block on `st`; parameter-gradient work is appended to D.
@@ -452,6 +453,7 @@ extern "C" int vlmo_stack_bwd(const VlmoStackDesc* s, hipStream_t st) {
                    "vlmo_stack_bwd: %d temporary sets cannot cover deferred batches of %d blocks", nsets, batch);
     Events& ev = events();
     Deferred D;
+    D.store = s->wgrad_store != 0;
     std::vector<int> batch_of(nb, -1);
     int n_batches = 0, waited_upto = -1;
     auto flush = [&]() -> int {

@@ -235,10 +235,12 @@ class GradReducer:
             self._pending_expect = getattr(self, '_pending_expect', {})
             self._pending_expect[key] = self._pending_expect.get(key, 0) + 1
 
-    def acquire(self, group, numel, device, arena_key=None, arena_numel=0, layout=None):
+    def acquire(self, group, numel, device, arena_key=None, arena_numel=0, layout=None, lazy_zero=False):
         """Flat fp32 storage for one parameter group of a block call.  ``arena_key`` (any hashable naming the block)
         places the groups of one block next to each other (``arena_numel`` = room for all of them) so that
-        release_all() can reduce them in one collective."""
+        release_all() can reduce them in one collective.  ``lazy_zero``: return ``(flat, fresh)`` and leave a fresh
+        bucket (first contribution of the accumulation window) UN-zeroed: the caller either overwrites it (the engine's
+        weight-gradient launch in store mode) or zeroes it itself."""
         key = self._key(group)
         sb = self.sinks.get(key)
         if sb is None:
@@ -259,10 +261,12 @@ class GradReducer:
             if self.on_gpu:
                 torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
             sb.work, sb.fresh, sb.unpacked, sb.reduced = None, True, False, False
-        if sb.fresh:
-            sb.flat.zero_()
+        fresh = sb.fresh
+        if fresh:
+            if not lazy_zero:
+                sb.flat.zero_()
             sb.fresh = False
-        return sb.flat[:numel]
+        return (sb.flat[:numel], fresh) if lazy_zero else sb.flat[:numel]
 
     def release(self, group):
         self.release_all([group])

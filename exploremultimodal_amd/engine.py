@@ -399,6 +399,7 @@ class BlockFn(torch.autograd.Function):
 WGRAD_BATCH = int(_os.environ.get('VLMO_WGRAD_BATCH', '2'))     # blocks per deferred weight-gradient launch
 TMP_SETS = int(_os.environ.get('VLMO_TMP_SETS', '4'))            # rotation depth of the backward temporaries
 USE_STACK = _os.environ.get('VLMO_STACK', '1') != '0'            # one native call per pass (else one per block)
+WGRAD_STORE = _os.environ.get('VLMO_WGRAD_STORE', '1') != '0'    # weight-gradient matrices written, not zero-filled + accumulated
 
 _PERSIST = {}
 
@@ -513,9 +514,12 @@ class StackFn(torch.autograd.Function):
         dx_in = torch.empty((M, d), dtype=f32, device=dev)
         if sink is None:
             tot = sum(shared_n + ((n_ - 11) // 4) * exp_n for (_, n_) in spans)
-            whole = torch.zeros(tot, dtype=f32, device=dev)       # ONE memset for every parameter gradient of the pass
+            # no memset of the weight-gradient matrices: the deferred launches WRITE them (wgrad_store); only the vector
+            # gradients (accumulated with atomics by the column folds) are zeroed, in one multi-tensor fill
+            whole = torch.empty(tot, dtype=f32, device=dev) if WGRAD_STORE else torch.zeros(tot, dtype=f32, device=dev)
         grads_all = [None] * len(params)
         goff = 0
+        store_ok, acquired = WGRAD_STORE, []      # (flat, fresh, is_expert) of every gradient bucket of the pass
         for k in range(nb):                 # backward order: k-th processed block is i = nb-1-k
             i = nb - 1 - k
             D = descs[i]
@@ -524,14 +528,19 @@ class StackFn(torch.autograd.Function):
             if sink is not None:
                 akey, aroom = id(params[o]), shared_n + 3 * exp_n
                 groups = ctx.sink_groups[i]
-                flats = [sink.acquire(groups[0], shared_n, dev, akey, aroom, layout=shared_layout(groups[0], d))] + \
-                        [sink.acquire(g_, exp_n, dev, akey, aroom, layout=expert_layout(g_, d, hid)) for g_ in groups[1:]]
+                got = [sink.acquire(groups[0], shared_n, dev, akey, aroom, layout=shared_layout(groups[0], d), lazy_zero=True)] + \
+                      [sink.acquire(g_, exp_n, dev, akey, aroom, layout=expert_layout(g_, d, hid), lazy_zero=True)
+                       for g_ in groups[1:]]
+                flats = [f_ for f_, _ in got]
+                store_ok = store_ok and all(fr for _, fr in got)      # a bucket an earlier pass of the step already fed: accumulate
+                acquired += [(f_, fr, j > 0) for j, (f_, fr) in enumerate(got)]
             else:
                 flats = [whole[goff:goff + shared_n]]
                 goff += shared_n
                 for e in range(nexp):
                     flats.append(whole[goff:goff + exp_n])
                     goff += exp_n
+                acquired += [(f_, True, j > 0) for j, f_ in enumerate(flats)]
             grads = _fill_grads(D, flats, d, hid, nexp)
             grads_all[o:o + n_] = grads
             st_ = k % nsets
@@ -544,8 +553,18 @@ class StackFn(torch.autograd.Function):
             D.dx1 = dxs.data_ptr() + 2 * md * 4
             D.dx2 = dxo.data_ptr() if k == 0 else dxs.data_ptr() + ((k - 1) % 2) * md * 4
             D.dx0 = dx_in.data_ptr() if k == nb - 1 else dxs.data_ptr() + (k % 2) * md * 4
+        if store_ok:
+            # vector gradients only: [g1 g2 n1w n1b n2w n2b | qkv_w proj_w | proj_b qkv_b] and [w1 | b1 | w2 | b2]
+            vecs = []
+            for f_, _, is_exp in acquired:
+                vecs += [f_[hid * d:hid * d + hid], f_[2 * hid * d + hid:]] if is_exp else [f_[:6 * d], f_[6 * d + 4 * d * d:]]
+            torch._foreach_zero_(vecs)
+        else:
+            for f_, fr, _ in acquired:
+                if fr and (sink is not None or WGRAD_STORE):
+                    f_.zero_()
         S = hip.StackDesc()
-        S.n_blocks, S.wgrad_batch, S.n_tmp_sets = nb, batch, nsets
+        S.n_blocks, S.wgrad_batch, S.n_tmp_sets, S.wgrad_store = nb, batch, nsets, int(store_ok)
         S.blocks = ctypes.cast(descs, ctypes.POINTER(hip.BlockDesc))
         side = _side_stream(dev) if OVERLAP_WGRAD else None
         S.side_stream = side.cuda_stream if side is not None else None

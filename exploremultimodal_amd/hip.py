@@ -58,7 +58,7 @@ class BlockDesc(ctypes.Structure):
 
 class StackDesc(ctypes.Structure):
     """Mirror of VlmoStackDesc (include/vlmo_hip.h)."""
-    _fields_ = [('n_blocks', _i32), ('wgrad_batch', _i32), ('n_tmp_sets', _i32), ('pad_', _i32),
+    _fields_ = [('n_blocks', _i32), ('wgrad_batch', _i32), ('n_tmp_sets', _i32), ('wgrad_store', _i32),
                 ('blocks', ctypes.POINTER(BlockDesc)), ('side_stream', _vp), ('grad_ready', ctypes.POINTER(_vp))]
 
 

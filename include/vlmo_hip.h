@@ -308,7 +308,7 @@ int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t stream);
  * vlmo_stack_bwd runs the activation-gradient chains of all blocks back to back on `stream` and defers the
  * parameter-gradient work (weight-gradient GEMMs, bias / layer-scale / LayerNorm column sums) to
  * `side_stream` in batches of `wgrad_batch` blocks, one vlmo_gemm_tn_multi + one vlmo_colwork_multi launch
- * per batch (parameter gradients are ACCUMULATED: zero or pre-load them).  Because that work runs later than
+ * per batch (parameter gradients are ACCUMULATED: zero or pre-load them; with wgrad_store only the vector ones).  Because that work runs later than
  * the block's own chain, the caller gives the k-th block in backward order its own backward temporaries
  * (dz2, du, dz1, dqkv) and column workspace ws_main (>= (3 + n_experts) * vlmo_reduce_ws_bytes(2*d) bytes),
  * rotating over n_tmp_sets > wgrad_batch sets (set k % n_tmp_sets); the call waits for a set's deferred readers
@@ -317,7 +317,9 @@ int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t stream);
  * vlmo_event_create): event i is recorded when block i's parameter gradients are complete, so a gradient
  * all-reduce on another stream can start per block (vlmo_stream_wait_event). */
 typedef struct VlmoStackDesc {
-    int32_t n_blocks, wgrad_batch, n_tmp_sets, pad_;
+    int32_t n_blocks, wgrad_batch, n_tmp_sets;
+    int32_t wgrad_store;        /* != 0: weight-gradient MATRICES are written (C = ...), not accumulated: no zero-fill, no
+                                 * read of C.  The vector gradients (biases, LayerNorm, layer-scale) always accumulate. */
     const VlmoBlockDesc* blocks;
     hipStream_t side_stream;
     void* const* grad_ready;
