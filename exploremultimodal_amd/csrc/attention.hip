@@ -28,6 +28,7 @@ struct AttnArgs {
     const bf16* dctx;     // bwd: grad of ctx
     bf16* out;            // fwd: ctx ; bwd: dqkv
     float* lse;
+    float* qvsum;        // bwd, optional: [num_seq][2 d] column sums of dq | dv over each sequence's tokens
     const int32_t* seg;
     const int32_t* keymask;
     int lse_stride, heads, d;
@@ -232,13 +233,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
 }
 
 // ------------------------------------------------------------------ backward
-// Two phases in one launch, sharing the Q/K/V/dO LDS images:
-//   dQ item   : a wavefront owns 32 queries, sweeps key tiles   -> dQ  (no reduction across waves)
-//   dK/dV item: a wavefront owns 32 keys,    sweeps query tiles -> dK, dV
-// The 2*nq items are independent once the images are staged, so the 8 waves pull them from one LDS
-// work counter, longest (dK/dV) first: 9+9 items at N=261 finish in ~40 units of work per wave instead of
-// the 56 of two statically scheduled phases (9 tiles over 8 waves = two rounds each).
-// P is recomputed from the forward's log-sum-exp; delta = rowsum(dO * O).
+// Column sums for the qkv-bias gradient (vlmo.py:71-75: q_bias / v_bias; the k third is a constant zero): t[dt][r] holds
+// feature dt * 32 + (r & 3) + 8 (r >> 2) + 4 h of the token on lane & 31.  Sum over the wave's 32 tokens (butterfly inside
+// each half-wave), scale, and add into acc[64] in LDS; tokens past the sequence carry weight 0.
+// inclusive DPP scan over each 32-lane half (gfx9 row_shr / row_bcast15 sequence): lanes 31 and 63 end up with their
+// half's total.  Six v_add_f32_dpp; the same sum through __shfl_xor is five ds_bpermute round trips per register and
+// made the two reductions of a wave cost more than the 51 MB re-read of dqkv they replace.
+template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float half_wave_total(float v) {
+    float s_ = v + dpp_mov<0x111, 0xf, 0xf>(v);         // row_shr:1 (lanes without a source read 0)
+    s_ += dpp_mov<0x112, 0xf, 0xf>(v);                  // row_shr:2
+    s_ += dpp_mov<0x113, 0xf, 0xf>(v);                  // row_shr:3  -> sums of 4
+    s_ += dpp_mov<0x114, 0xf, 0xe>(s_);                 // row_shr:4, banks 1-3 -> sums of 8
+    s_ += dpp_mov<0x118, 0xf, 0xc>(s_);                 // row_shr:8, banks 2-3 -> lane 15 of a row = the row's total
+    s_ += dpp_mov<0x142, 0xa, 0xf>(s_);                 // row_bcast15 into rows 1 and 3 -> lanes 31 / 63 = half totals
+    return s_;
+}
+__device__ __forceinline__ void colsum_tiles(const f32x16* t, float w, float scale, float* acc, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = half_wave_total(t[dt][r] * w);
+            if ((lane & 31) == 31) atomicAdd(acc + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, v * scale);
+        }
+}
+
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, const int NPAD) {
     const int IMG = NPAD * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,6 +274,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     float* delta = lseq + NPAD;
     int* rowidx = (int*)(delta + NPAD);
     int* next_item = rowidx + NPAD;
+    float* csum = (float*)(next_item + 4);      // [2][64]: column sums of dq | dv of this (sequence, head)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     int N;
     setup_rows(a.seg, sidx, a.keymask, NPAD, rowidx, kbias, N);
     if (threadIdx.x == 0) *next_item = 0;
+    if (threadIdx.x < 128) csum[threadIdx.x] = 0.f;
     __syncthreads();
     const int nq = (N + 31) >> 5;   // query tiles == key tiles (self-attention)
     stage_image<8>(a.qkv, ld, hd * 64, rowidx, Qimg, nq * 4, wave, lane);
@@ -291,10 +316,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     // applied ONCE to the 32 accumulator values a lane owns, not to every score element
     const float out_scale = a.scale * a.inv_keep;
 
+    // running column sums of the tiles this wave finishes (a.qvsum): one kind at a time -- items are handed out dK/dV
+    // first, then dQ, so a wave switches at most once -- reduced over the lanes when the kind changes and at the end
+    f32x16 cs[2] = {zero16(), zero16()};
+    int cs_kind = -1;
     for (;;) {
     int item = 0;
     if (lane == 0) item = atomicAdd(next_item, 1);
     item = __builtin_amdgcn_readfirstlane(item);
+    if (a.qvsum) {
+        const int kind = item >= 2 * nq ? -1 : (item >= nq ? 0 : 1);        // 0: dq sums, 1: dv sums
+        if (cs_kind >= 0 && kind != cs_kind) {
+            colsum_tiles(cs, 1.f, cs_kind == 0 ? out_scale : a.inv_keep, csum + 64 * cs_kind, lane);
+            cs[0] = zero16(), cs[1] = zero16();
+        }
+        cs_kind = kind;
+    }
     if (item >= 2 * nq) break;
     // ---- dQ item: dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
     if (item >= nq) {
@@ -341,6 +378,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                         dQ[dt] = Elem<bf16>::mfma(tr_frag(Kimg, kt * 32 + 16 * s2, dt * 32, lane), sf, dQ[dt]);
                 }
             }
+        }
+        if (a.qvsum) {
+            const float wq = qi < N ? 1.f : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cs[dt][r] = fmaf(dQ[dt][r], wq, cs[dt][r]);
         }
         if (qi < N) {
             bf16* op = a.out + (size_t)rowidx[qi] * ld + hd * 64 + 4 * h;
@@ -411,6 +455,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                 }
             }
         }
+        if (a.qvsum) {
+            const float wk = ki < N ? 1.f : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cs[dt][r] = fmaf(dV[dt][r], wk, cs[dt][r]);
+        }
         if (ki < N) {
             bf16* op = a.out + (size_t)rowidx[ki] * ld + hd * 64 + 4 * h;
 #pragma unroll
@@ -426,6 +477,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
                 }
         }
     }
+    }
+    if (a.qvsum) {
+        __syncthreads();
+        if (threadIdx.x < 128)
+            a.qvsum[(size_t)sidx * 2 * a.d + (threadIdx.x >> 6) * a.d + hd * 64 + (threadIdx.x & 63)] = csum[threadIdx.x];
     }
 }
 
@@ -468,6 +524,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
     float* kbias = (float*)(slots + 2 * nt * 2048);
     float* nlq = kbias + NPAD;      // -lse / scale per query (-inf on padded queries)
     float* ndl = nlq + NPAD;        // -delta * keep_prob
+    float* csum = ndl + NPAD;       // [2][64]: column sums of dq | dv of this (sequence, head)
 
 
     const int lane = threadIdx.x & 63;
@@ -509,6 +566,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
             vf[s] = *(const bf16x8*)(kp + a.d + 16 * s);
         }
     }
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) csum[i] = 0.f;      // a one-tile launch has 64 threads
     const float keep_prob = 1.f / a.inv_keep;
     const float inv_scale = 1.f / a.scale;
     for (int i = threadIdx.x; i < NPAD; i += blockDim.x) {
@@ -749,6 +807,16 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
                 *(bf16x4*)(op + 2 * a.d + dt * 32 + 8 * g4) = ov;
             }
     }
+    if (a.qvsum) {
+        if (active) {
+            const float wt = ki < N ? 1.f : 0.f;
+            colsum_tiles(dQ, wt, out_scale, csum, lane);
+            colsum_tiles(dV, wt, a.inv_keep, csum + 64, lane);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 128; i += blockDim.x)
+            a.qvsum[(size_t)sidx * 2 * a.d + (i >> 6) * a.d + hd * 64 + (i & 63)] = csum[i];
+    }
 }
 
 // dynamic-LDS limit already raised for a kernel on a device (a process may drive several GPUs)
@@ -776,7 +844,7 @@ int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     return 0;
 }
 int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
-    const int LDS = nt * 32 * 512 + nt * 32 * 16 + 16;
+    const int LDS = nt * 32 * 512 + nt * 32 * 16 + 32 + 512;
     int& max_set = lds_limit_set(1);
     if (LDS > max_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -787,7 +855,7 @@ int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
 }
 
 int launch_bwd1(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
-    const int LDS = nt * 32 * 384 + 2 * nt * 2048 + nt * 32 * 16;
+    const int LDS = nt * 32 * 384 + 2 * nt * 2048 + nt * 32 * 12 + 512;
     int& max_set = lds_limit_set(2);
     if (LDS > max_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -836,9 +904,9 @@ extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, c
 }
 
 extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, int lse_stride,
-                             const int32_t* seg, int num_seq, const int32_t* keymask, void* dqkv, int heads, int d,
-                             int max_len, float scale, uint32_t drop_thresh, float inv_keep, uint64_t seed,
-                             hipStream_t stream) {
+                             const int32_t* seg, int num_seq, const int32_t* keymask, void* dqkv, float* qv_colsum,
+                             int heads, int d, int max_len, float scale, uint32_t drop_thresh, float inv_keep,
+                             uint64_t seed, hipStream_t stream) {
     if (int rc = check_common("vlmo_attn_bwd", qkv, seg, num_seq, heads, d, max_len, 288)) return rc;
     VLMO_CHECK_ARG(ctx && dctx && lse && dqkv, "vlmo_attn_bwd: null pointer");
     VLMO_CHECK_ARG(lse_stride >= max_len, "vlmo_attn_bwd: lse_stride too small");
@@ -847,6 +915,7 @@ extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx,
     a.ctx = (const bf16*)ctx;
     a.dctx = (const bf16*)dctx;
     a.out = (bf16*)dqkv;
+    a.qvsum = qv_colsum;
     a.lse = (float*)lse;
     a.seg = seg;
     a.keymask = keymask;

@@ -221,7 +221,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)(d / b->heads));
     for (int a = 0; a < b->n_attn; ++a)
         TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
-                          b->dqkv, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
+                          b->dqkv, nullptr, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
                           b->seed + 11 + a, st));
     fork();     // one fork for the whole attention half: the proj gradient waits for it too (the side stream has slack)
     TRY(reduce_partials(pend[0], side));
@@ -379,16 +379,34 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D, const
         TRY(vlmo_gemm_nt(VLMO_EPI_BIAS, VLMO_BF16, b->tile, b->dz1, d, b->proj_wT, d, M, d, d, &e, st));
     }
     const float scale = 1.0f / sqrtf((float)(d / b->heads));
-    for (int a = 0; a < b->n_attn; ++a)
+    // q_bias / v_bias gradient = column sums of the q and v thirds of dqkv (the k third of the bias is a constant zero,
+    // vlmo.py:71-75, and its gradient vanishes anyway: the soft-max is invariant to a shift of the scores along the
+    // keys).  The attention backward leaves them per sequence ([sequences][2d], behind the other column partials of
+    // this block's workspace) and the batched column kernel folds 64-128 rows instead of reading 51 MB of dqkv again.
+    int nseq_all = 0;
+    for (int a = 0; a < b->n_attn; ++a) nseq_all += b->nseq[a];
+    float* qvsum = nullptr;
+    if ((colpart_off + (int64_t)nseq_all * 2 * d) * 4 <= b->ws_bytes) qvsum = (float*)b->ws_main + colpart_off;
+    for (int a = 0, s0 = 0; a < b->n_attn; s0 += b->nseq[a], ++a)
         TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
-                          b->dqkv, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
-                          b->seed + 11 + a, st));
+                          b->dqkv, qvsum ? qvsum + (size_t)s0 * 2 * d : nullptr, b->heads, d, b->maxlen[a], scale,
+                          b->attn_drop_thresh, b->attn_inv_keep, b->seed + 11 + a, st));
     push_tn(D, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d);
     push_tn(D, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d);
-    // q and v thirds only: the k third of the bias is a constant zero (vlmo.py:71-75), and its gradient vanishes
-    // anyway (the soft-max is invariant to a shift of the scores along the keys)
-    push_colsum(D, b->dqkv, 3 * d, M, d, b->dqkv_b);
-    push_colsum(D, bp(b->dqkv, 0, 0, 2) + 4 * (size_t)d, 3 * d, M, d, b->dqkv_b + 2 * d);
+    if (qvsum) {
+        VlmoColJob j{};
+        j.kind = 0;
+        j.ld = 2 * d;
+        j.src = qvsum;
+        j.rows = nseq_all;
+        j.ncols = 2 * d;
+        j.out[0] = b->dqkv_b, j.out[1] = b->dqkv_b + 2 * d;
+        j.n0 = d;
+        D.col.push_back(j);
+    } else {
+        push_colsum(D, b->dqkv, 3 * d, M, d, b->dqkv_b);
+        push_colsum(D, bp(b->dqkv, 0, 0, 2) + 4 * (size_t)d, 3 * d, M, d, b->dqkv_b + 2 * d);
+    }
     {
         VlmoEpilogue e = epi();
         e.out = b->dy1;

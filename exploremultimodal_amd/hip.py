@@ -84,7 +84,7 @@ _SIGS = {
                           _i32, _i32, _vp, _i64, _vp],
     'vlmo_attn_fwd': [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _f32,
                       _u64, _vp],
-    'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f32,
+    'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
                       _u32, _f32, _u64, _vp],
     'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp, _i64, _vp],
     'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp],
@@ -121,7 +121,7 @@ _SIGS = {
 }
 
 _lib = None
-ABI_VERSION = 3      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
+ABI_VERSION = 4      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
 
 def lib():
     """Load (once) and return the C-ABI library; raise loudly if it is missing."""
@@ -283,9 +283,9 @@ def attn_fwd(qkv, seg, nseq, keymask, ctx, lse, heads, d, max_len, scale, drop=(
 
 
 def attn_bwd(qkv, ctx, dctx, lse, seg, nseq, keymask, dqkv, heads, d, max_len, scale,
-             drop=(0, 1.0), seed=0):
+             drop=(0, 1.0), seed=0, qv_colsum=None):
     rc = lib().vlmo_attn_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), lse.stride(0), _p(seg), nseq,
-                             _p(keymask), _p(dqkv), heads, d, max_len, scale, drop[0], drop[1],
+                             _p(keymask), _p(dqkv), _p(qv_colsum), heads, d, max_len, scale, drop[0], drop[1],
                              seed & 0xFFFFFFFFFFFFFFFF, _stream())
     _check(rc, 'vlmo_attn_bwd')
 

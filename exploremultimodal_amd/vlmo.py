@@ -93,10 +93,13 @@ class Attention(nn.Module):
             raise NotImplementedError('qk_scale override is not supported')
         self.scale = head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=False)
-        if not qkv_bias:
-            raise NotImplementedError('qkv_bias=False is not supported (all reference configs use True)')
-        self.q_bias = nn.Parameter(torch.zeros(dim))
-        self.v_bias = nn.Parameter(torch.zeros(dim))
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:       # vlmo.py:60-62: no bias parameters; the engine is handed a constant zero vector instead
+            self.q_bias = None
+            self.v_bias = None
+            self.register_buffer('_zero_bias', torch.zeros(dim), persistent=False)
         self.attn_drop = attn_drop
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = proj_drop
@@ -121,13 +124,16 @@ class Block(nn.Module):
         if init_values is not None and init_values > 0:
             self.gamma_1 = nn.Parameter(init_values * torch.ones((dim)), requires_grad=True)
             self.gamma_2 = nn.Parameter(init_values * torch.ones((dim)), requires_grad=True)
-        else:
-            raise NotImplementedError('init_values must be > 0 (layer-scale is part of every reference config)')
+        else:       # vlmo.py:185-186, 190-192: no layer-scale; the engine multiplies by a constant vector of ones
+            self.gamma_1, self.gamma_2 = None, None
+            self.register_buffer('_unit_scale', torch.ones(dim), persistent=False)
 
     # -- engine plumbing -----------------------------------------------------
     def _params(self, routes):
         a = self.attn
-        ps = [self.gamma_1, self.gamma_2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias,
+        g1, g2 = (self.gamma_1, self.gamma_2) if self.gamma_1 is not None else (self._unit_scale, self._unit_scale)
+        qb, vb = (a.q_bias, a.v_bias) if a.q_bias is not None else (a._zero_bias, a._zero_bias)
+        ps = [g1, g2, self.norm1.weight, self.norm1.bias, a.qkv.weight, qb, vb,
               a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias]
         for r in routes:
             m = self.mlp[r]

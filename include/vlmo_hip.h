@@ -153,10 +153,12 @@ int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, const int32_
                   void* ctx, float* lse, int lse_stride, int heads, int d, int max_len,
                   float scale, uint32_t drop_thresh, float inv_keep, uint64_t seed,
                   hipStream_t stream);
+/* qv_colsum (optional, [num_seq][2 d] fp32, written): per sequence the column sums of its tokens' dq | dv rows -- the
+ * q_bias / v_bias gradient (vlmo.py:71-75) is their sum over the sequences, so nobody re-reads dqkv for it. */
 int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                   int lse_stride, const int32_t* seg, int num_seq, const int32_t* keymask,
-                  void* dqkv, int heads, int d, int max_len, float scale, uint32_t drop_thresh,
-                  float inv_keep, uint64_t seed, hipStream_t stream);
+                  void* dqkv, float* qv_colsum, int heads, int d, int max_len, float scale,
+                  uint32_t drop_thresh, float inv_keep, uint64_t seed, hipStream_t stream);
 
 /* Residual-branch backward (vlmo.py:194-196): dz = dx * gamma * row_scale * dropmask/(1-p);
  * dgamma += sum_m dx * row_scale * zd;  dbias += sum_m dz. */

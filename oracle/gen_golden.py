@@ -121,9 +121,9 @@ def out_weights(mode, shape):
     return _normal(4242, 'R:' + mode, shape)
 
 
-def run_backbone_case(name, preset, B, with_grads=True, full_out=True, seed=0, full_grad_max=16384):
+def run_backbone_case(name, preset, B, with_grads=True, full_out=True, seed=0, full_grad_max=16384, **model_over):
     from oracle import synth
-    cfg = synth.make_config(preset)
+    cfg = synth.make_config(preset, **model_over)
     mc = cfg.model
     all_experts = [('v', 'l', 'vl')] * mc.depth
     sd = synth.synth_backbone_state_dict(mc, seed, all_experts)
@@ -307,6 +307,8 @@ def main():
     cases = {
         'backbone_mini': lambda: run_backbone_case('backbone_mini', 'mini', B=3),
         'backbone_small': lambda: run_backbone_case('backbone_small', 'small', B=2),
+        # the optional branches of the reference: no q/v bias (vlmo.py:57-62), no layer-scale (vlmo.py:185-192)
+        'backbone_mini_plain': lambda: run_backbone_case('backbone_mini_plain', 'mini', B=3, qkv_bias=False, init_values=None),
         'backbone_debug': lambda: run_backbone_case('backbone_debug', 'debug', B=2),
         'backbone_base_b2': lambda: run_backbone_case('backbone_base_b2', 'base', B=2, full_out=False),
         # VLMo-Large (conf/model/vlmo_large.yaml:14-28: d=1024, L=24, h=16, F=12); the synthetic layer-scale stays

@@ -30,9 +30,11 @@ def attention(sd, p, x, mask, num_heads):
     """vlmo.py:68-98.  Returns (out, attn_probs)."""
     B, N, C = x.shape
     dh = C // num_heads
-    qkv_bias = torch.cat((sd[p + 'q_bias'],
-                          torch.zeros_like(sd[p + 'v_bias']),
-                          sd[p + 'v_bias']))
+    qkv_bias = None             # qkv_bias=False: no q_bias / v_bias parameters (vlmo.py:57-62, 70-75)
+    if p + 'q_bias' in sd:
+        qkv_bias = torch.cat((sd[p + 'q_bias'],
+                              torch.zeros_like(sd[p + 'v_bias']),
+                              sd[p + 'v_bias']))
     qkv = F.linear(x, sd[p + 'qkv.weight'], qkv_bias)
     qkv = qkv.reshape(B, N, 3, num_heads, dh).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
@@ -51,15 +53,16 @@ def mlp(sd, p, x):
 
 
 def block(sd, i, x, mask, route, num_heads):
-    """vlmo.py:187-197 (gamma branch; eval-mode DropPath = identity)."""
+    """vlmo.py:187-197 (both branches; eval-mode DropPath = identity)."""
     p = f'blocks.{i}.'
     a, _ = attention(sd, p + 'attn.',
                      layer_norm(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias']),
                      mask, num_heads)
-    x = x + sd[p + 'gamma_1'] * a
+    has_gamma = p + 'gamma_1' in sd         # init_values=None: no layer-scale (vlmo.py:158-162, 190-192)
+    x = x + (sd[p + 'gamma_1'] * a if has_gamma else a)
     m = mlp(sd, p + f'mlp.{route}.',
             layer_norm(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias']))
-    x = x + sd[p + 'gamma_2'] * m
+    x = x + (sd[p + 'gamma_2'] * m if has_gamma else m)
     return x
 
 

@@ -20,9 +20,12 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def build(preset, **over):
+PLAIN = dict(qkv_bias=False, init_values=None)      # the reference's optional branches (vlmo.py:57-62, 185-192)
+
+
+def build(preset, model_over=None, **over):
     from exploremultimodal_amd.vlmo import VLMO, LayerNorm
-    mc = synth.make_config(preset).model
+    mc = synth.make_config(preset, **(model_over or {})).model
     m = VLMO(img_size=mc.img_size, patch_size=mc.patch_size, in_chans=mc.in_chans, num_classes=mc.num_classes,
              embed_dim=mc.embed_dim, depth=mc.depth, num_heads=mc.num_heads, mlp_ratio=mc.mlp_ratio,
              qkv_bias=mc.qkv_bias, drop_rate=over.get('drop', 0.0), attn_drop_rate=over.get('drop', 0.0),
@@ -49,11 +52,15 @@ def modes(mc, batch, B):
 
 
 @pytest.mark.parametrize('name,preset', [('backbone_mini', 'mini'), ('backbone_small', 'small'),
-                                         ('backbone_base_b2', 'base'), ('backbone_large_b2', 'large')])
+                                         ('backbone_base_b2', 'base'), ('backbone_large_b2', 'large'),
+                                         ('backbone_mini_plain', 'mini')])
 def test_forward_backward_matches_reference(golden_dir, name, preset):
+    """backbone_mini_plain: qkv_bias=False and init_values=None (no q/v bias, no layer-scale parameters)."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     B = int(g['meta.B'])
-    model, mc = build(preset)
+    model, mc = build(preset, PLAIN if name.endswith('_plain') else None)
+    if name.endswith('_plain'):
+        assert not any('gamma_' in k or 'q_bias' in k or 'v_bias' in k for k in model.state_dict())
     model.eval()
     batch = synth.synth_batch(mc, B, seed=1234)
     report = []
@@ -246,7 +253,8 @@ def test_native_stack_path_equals_per_block_path(preset, B):
     gradient chain is the same too, so what differs is only the summation order inside the weight gradients and
     column sums (fp32: 1e-4 of the gradient's largest element) -- except the fc1 bias gradient, which the stack path
     folds from the fp32 values in the GELU-derivative epilogue while the per-block path sums the bf16-rounded du
-    matrix afterwards (bf16 rounding of every addend: 4e-3)."""
+    matrix afterwards (bf16 rounding of every addend: 4e-3), and likewise q_bias / v_bias (folded from the attention
+    backward's fp32 accumulators per sequence vs summed from the bf16 dqkv matrix)."""
     from exploremultimodal_amd import engine
     model, mc = build(preset, drop=0.1, drop_path=0.1)
     model.train()
@@ -264,7 +272,7 @@ def test_native_stack_path_equals_per_block_path(preset, B):
     assert torch.equal(xs, xb), (xs - xb).abs().max()
     assert set(gs) == set(gb)
     for n in gb:
-        tol = (4e-3 if n.endswith('fc1.bias') else 1e-4) * gb[n].abs().max().item() + 1e-9
+        tol = (4e-3 if n.endswith(('fc1.bias', 'q_bias', 'v_bias')) else 1e-4) * gb[n].abs().max().item() + 1e-9
         assert (gs[n] - gb[n]).abs().max().item() <= tol, (n, (gs[n] - gb[n]).abs().max().item(), tol)
 
 

@@ -297,7 +297,7 @@ def _attn_ref(qkv, seg, keymask, heads, d, dctx=None, keep=None, inv_keep=1.0):
 
 
 @pytest.mark.parametrize('B,lenA,lenB,heads', [(3, 16, 17, 2), (2, 64, 0, 2), (2, 0, 197, 1),
-                                               (2, 64, 197, 2), (1, 40, 197, 3), (2, 24, 50, 4)])
+                                               (2, 64, 197, 2), (1, 40, 197, 3), (2, 24, 50, 4), (3, 16, 0, 2), (2, 0, 256, 1)])
 def test_attention_fwd_bwd(B, lenA, lenB, heads):
     qkv, seg, keymask, M, d = _attn_case(B, lenA, lenB, heads, seed=B + lenA)
     N = lenA + lenB
@@ -308,9 +308,15 @@ def test_attention_fwd_bwd(B, lenA, lenB, heads):
     ref_ctx, ref_dqkv = _attn_ref(qkv, seg, keymask, heads, d, dctx)
     _close(ctx, ref_ctx, 1 / 64, 1e-2, 'attn ctx')
     dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
-    hip.attn_bwd(qkv, ctx, dctx, lse.view(B * heads, -1), seg, B, keymask, dqkv, heads, d, N, 64 ** -0.5)
+    qv = torch.full((B, 2 * d), float('nan'), device=DEV)
+    hip.attn_bwd(qkv, ctx, dctx, lse.view(B * heads, -1), seg, B, keymask, dqkv, heads, d, N, 64 ** -0.5, qv_colsum=qv)
     scale = ref_dqkv.abs().max().item()
     _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * scale, 'attn dqkv')
+    # per-sequence column sums of dq | dv (what the q_bias / v_bias gradient is folded from)
+    for si, sg in enumerate(seg.tolist()):
+        rows = torch.cat([torch.arange(sg[0], sg[0] + sg[1]), torch.arange(sg[2], sg[2] + sg[3])]).to(DEV)
+        want = torch.cat([ref_dqkv[rows, :d].sum(0), ref_dqkv[rows, 2 * d:].sum(0)])
+        _close(qv[si], want, 1 / 32, 2e-2 * scale * max(1.0, len(rows) ** 0.5), 'attn qv column sums')
 
 
 def test_attention_mixed_lengths_in_one_launch():
