@@ -250,6 +250,29 @@ def _fill_forward(D, meta, params, launches, lse_sizes, M, pb, pf, need_bwd, kee
         keep += [a, at, c, ct]
 
 
+SPLIT_BWD_ATTENTION = _os.environ.get('VLMO_SPLIT_BWD_ATTN', '1') != '0'
+
+
+def _split_backward_attention(D, meta):
+    """Below the fusion layer the image and the text sequences share ONE forward attention launch (Plan.seg_sep, image
+    sequences first).  The single-pass backward sizes a workgroup (one wave per key tile, LDS images) for the launch's
+    LONGEST sequence, so in the shared launch every 64-token text sequence would hold a whole CU with 2 of 7 waves
+    working (122 us for the pair at Base B=64); as two launches the text one takes 34 KB of LDS and 128 threads per
+    workgroup, four to a CU (79 + 16 us).  The forward's log-sum-exp buffer is addressed per sequence with the shared
+    launch's stride, so the two backward launches are views of it."""
+    pl = meta.plan
+    if (not SPLIT_BWD_ATTENTION or meta.fused or D.n_attn != 1 or pl.seg_sep is None or not (pl.T and pl.P)
+            or D.nseq[0] != 2 * pl.B or max(pl.T, pl.P) > 256):
+        return
+    stride = D.lse_stride[0]
+    D.n_attn = 2
+    D.nseq[0], D.nseq[1] = pl.B, pl.B
+    D.maxlen[0], D.maxlen[1] = pl.P, pl.T
+    D.lse_stride[1] = stride
+    D.seg[1] = D.seg[0] + pl.B * 16                                       # 4 int32 per sequence
+    D.lse[1] = D.lse[0] + pl.B * meta.heads * stride * 4
+
+
 def _carve(flat, shapes):
     out, off = [], 0
     for shp in shapes:
@@ -356,6 +379,7 @@ class BlockFn(torch.autograd.Function):
             flats = [whole[:shared_n]] + [whole[shared_n + i * exp_n: shared_n + (i + 1) * exp_n] for i in range(nexp)]
 
         grads = _fill_grads(D, flats, d, hid, nexp)
+        _split_backward_attention(D, meta)
         # temporaries: dz2 | du(4) | dy2(=dctx) | dz1 | dqkv(3) | dy1  bf16 ; dx1, dx0 fp32
         tb = torch.empty(11 * M * d, dtype=torch.bfloat16, device=dev)
         dx1 = torch.empty((M, d), dtype=f32, device=dev)
@@ -544,6 +568,7 @@ class StackFn(torch.autograd.Function):
                 acquired += [(f_, True, j > 0) for j, f_ in enumerate(flats)]
             grads = _fill_grads(D, flats, d, hid, nexp)
             grads_all[o:o + n_] = grads
+            _split_backward_attention(D, metas[i])
             st_ = k % nsets
             pb = tb.data_ptr() + st_ * 11 * md * 2
             md2 = md * 2
