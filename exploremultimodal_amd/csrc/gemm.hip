@@ -106,7 +106,7 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, in
     const RowAddr o{(size_t)gmb * e.ldo, (uint32_t)(row * e.ldo + gn)};
     const RowAddr o2{(size_t)gmb * e.ld2, (uint32_t)(row * e.ld2 + gn)};
     if constexpr (EPI == EPI_BIAS) {
-        const float lo = e.relu ? 0.f : -INFINITY;
+        const float lo = (e.relu & 1) ? 0.f : -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
         pin4(v);
@@ -362,6 +362,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             for (int i = 0; i < TM; ++i) af[ks][i] = *(const v8*)(s + a_row_off + i * 32 * ROWB + coff);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[ks][j] = *(const v8*)(s + b_row_off + j * 32 * ROWB + coff);
+        }
+        if constexpr (CONV && sizeof(T) == 2 && __is_same(T, f16)) {
+            // ReLU on the INPUT (VlmoEpilogue.relu bit 1): the dVAE's residual path convolves relu(x) (encoder.py:21-29)
+            // while the identity path and the max-pool take x itself, so the producer would have to write both; four
+            // v_pk_max_f16 per fragment beside 4-8 MFMAs are cheaper than a second [B*H*W, C] tensor through HBM
+            if (pp->e.relu & 2) {
+                const v8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[ks][i] = __builtin_elementwise_max(af[ks][i], z);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -1361,6 +1373,10 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     p.ngroups = 1;
     p.g[0] = GemmNT{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8};
     ProfScope prof(32 + epi, 2.0 * B * H * W * Cout * K, stream);
+    // <= 64 output channels (the bottleneck convolutions of the dVAE's first group, 112 x 112 x 64): a 256 x 64 tile --
+    // with the 128-wide tile half of every MFMA and half of the weight staging multiplied padding
+    if (dtype == VLMO_F16 && Cout <= 64 && epi == EPI_BIAS)
+        return launch_nt<f16, 256, 64, 4, 1, true, 64, 2, false, (1u << EPI_BIAS)>(epi, p, stream);
     if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);
 }

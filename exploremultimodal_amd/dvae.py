@@ -151,8 +151,10 @@ class Encoder(nn.Module):
         M = B * H * W
         cols = em(M, ws.shape[1])
         hip.dvae_im2col(x, cols, stem.kw, ws.shape[1])
-        raw, rel = em(M, self.n_hid), em(M, self.n_hid)
-        hip.gemm_nt(hip.EPI_DUAL, cols, ws, M, self.n_hid, ws.shape[1], raw, out2=rel, bias=bs, beta=1.0)
+        # only the raw feature map of every stage goes to HBM: the residual path's first convolution applies the ReLU to
+        # its input fragments (relu_in), the identity path and the max-pool read the map as it is (encoder.py:21-29, 45-46)
+        raw, rel = em(M, self.n_hid), None
+        hip.gemm_nt(hip.EPI_DUAL, cols, ws, M, self.n_hid, ws.shape[1], raw, bias=bs, beta=1.0)
         del cols
         h, w = H, W
         for g in range(1, 5):
@@ -160,13 +162,13 @@ class Encoder(nn.Module):
             for bi in range(1, self.n_blk_per_group + 1):
                 blk = getattr(grp, f'block_{bi}')
                 hid, n_out = blk.n_hid, blk.n_out
-                t = rel
+                t = raw
                 c_in = blk.n_in
                 for ci in (1, 2, 3):
                     conv = getattr(blk.res_path, f'conv_{ci}')
                     wq, bq = conv.shadow()
                     o = em(M, hid)
-                    hip.conv2d_nhwc(hip.EPI_BIAS, t, B, h, w, c_in, 3, wq, hid, o, bias=bq, relu=True)
+                    hip.conv2d_nhwc(hip.EPI_BIAS, t, B, h, w, c_in, 3, wq, hid, o, bias=bq, relu=True, relu_in=(ci == 1))
                     t, c_in = o, hid
                 if isinstance(blk.id_path, Conv2d):
                     wi, bi_ = blk.id_path.shadow()
@@ -175,16 +177,17 @@ class Encoder(nn.Module):
                 else:
                     idp = raw
                 w4, b4 = blk.res_path.conv_4.shadow()
-                raw2, rel2 = em(M, n_out), em(M, n_out)
+                last = g == 4 and bi == self.n_blk_per_group     # the output convolution (a plain GEMM) reads relu(x)
+                raw2, rel2 = em(M, n_out), (em(M, n_out) if last else None)
                 hip.gemm_nt(hip.EPI_DUAL, t, w4, M, n_out, hid, raw2, out2=rel2, bias=b4, resid=idp,
                             beta=blk.post_gain)
                 raw, rel = raw2, rel2
             if g < 4:
                 C2 = raw.shape[1]
                 Mp = B * (h // 2) * (w // 2)
-                rp, lp = em(Mp, C2), em(Mp, C2)
-                hip.maxpool2_nhwc(raw, rp, lp, B, h, w, C2)
-                raw, rel, h, w, M = rp, lp, h // 2, w // 2, Mp
+                rp = em(Mp, C2)
+                hip.maxpool2_nhwc(raw, rp, None, B, h, w, C2)
+                raw, rel, h, w, M = rp, None, h // 2, w // 2, Mp
         return rel, (B, h, w)
 
     def forward(self, x):

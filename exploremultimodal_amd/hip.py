@@ -362,10 +362,11 @@ def zero_page(device):
 
 
 def conv2d_nhwc(epi, x, B, H, W, Cin, kw, w, Cout, out, *, out2=None, bias=None, resid=None, relu=False,
-                beta=0.0, ldo=None):
+                relu_in=False, beta=0.0, ldo=None):
+    """relu: ReLU on the output; relu_in: the convolution reads relu(x) (applied to the fragments, x stays as it is)."""
     e = Epilogue(_p(out), _p(out2), _p(bias), None, _p(resid), None, None, None,
                  ldo if ldo is not None else out.stride(0), out2.stride(0) if out2 is not None else 0,
-                 int(relu), 0, 1.0, beta, 0)
+                 int(relu) | (2 if relu_in else 0), 0, 1.0, beta, 0)
     rc = lib().vlmo_conv2d_nhwc(epi, _dt(x), _p(x), B, H, W, Cin, kw, _p(w), Cout, _p(zero_page(x.device)),
                                 ctypes.byref(e), _stream())
     _check(rc, 'vlmo_conv2d_nhwc')
