@@ -13,6 +13,11 @@ python3 bench.py --steps 40 --warmup 10 "$@" > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done" >> $OUT/progress.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline "$@" > $OUT/stats.log 2>&1
 echo "stats done" >> $OUT/progress.txt
+# the same step with the weight-gradient work on the main stream: kernel durations without CU sharing between streams
+VLMO_OVERLAP_WGRAD=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/serial -o s --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline "$@" > $OUT/serial.log 2>&1
+echo "serial stats done" >> $OUT/progress.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/dvae -o s --output-format csv -- python3 tools/dvae_bench.py > $OUT/dvae.log 2>&1
+echo "dvae stats done" >> $OUT/progress.txt
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o c --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline "$@" > $OUT/$C.log 2>&1
   echo "$C done" >> $OUT/progress.txt
@@ -23,4 +28,9 @@ python3 tools/summarize_pmc.py $TAG $TOTAL $MS --stats $OUT/stats/s_kernel_stats
 cp $OUT/stats/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 python3 tools/summarize_profile.py $OUT/stats/s_kernel_stats.csv $TOTAL > $OUT/${TAG}_summary.json
 cp $OUT/bench.json $OUT/${TAG}_bench.json
+cp $OUT/serial/s_kernel_stats.csv $OUT/${TAG}_serial_kernel_stats.csv
+python3 tools/summarize_profile.py $OUT/serial/s_kernel_stats.csv $TOTAL > $OUT/${TAG}_serial_summary.json
+cp $OUT/dvae/s_kernel_stats.csv $OUT/${TAG}_dvae_kernel_stats.csv
+python3 tools/summarize_profile.py $OUT/dvae/s_kernel_stats.csv 7 > $OUT/${TAG}_dvae_summary.json
+grep "images/s" $OUT/dvae.log > $OUT/${TAG}_dvae_bench.txt
 ls -la $OUT | tail -20
