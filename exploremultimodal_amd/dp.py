@@ -92,24 +92,25 @@ class _SinkBucket:
         self.has_grad = False   # a collective has been issued for it in the current accumulation window
 
 
-def _all_reduce(comm, pg, world, rs_ag):
-    """Average-ready sum of a flat bucket over the ranks.  rs_ag (VLMO_DP_COLLECTIVE=rs_ag): the same result as a
-    reduce-scatter + all-gather pair on the bucket in place (what a ring all-reduce is made of, issued as the two
-    collectives RCCL schedules over all xGMI links) -- an A/B switch for the first multi-GPU run."""
-    if rs_ag and world > 1 and comm.numel() % world == 0:
-        n = comm.numel() // world
-        rank = dist.get_rank(pg)
-        mine = comm[rank * n:(rank + 1) * n]
-        dist.reduce_scatter_tensor(mine, comm, group=pg)
-        return dist.all_gather_into_tensor(comm, mine, group=pg, async_op=True)
-    return dist.all_reduce(comm, group=pg, async_op=True)
+class _Enqueued:
+    """Work handle of a collective issued through the C-ABI communicator: it is ordered by the stream it was enqueued
+    on, there is nothing to wait for on the host."""
+    def wait(self):
+        return True
 
 
 class GradReducer:
     def __init__(self, module, process_group=None, comm_dtype=torch.bfloat16, reduce_scatter=False,
-                 broadcast_params=True, engine_sink=True):
+                 broadcast_params=True, engine_sink=True, comm=None):
+        """comm: 'torch' (collectives through torch.distributed, backend nccl = RCCL) or 'native' (the library's own RCCL
+        communicator, include/vlmo_hip.h vlmo_comm_*: the collectives are plain enqueues on the communication stream);
+        default from VLMO_DP_COMM, else 'torch'."""
         import os
         self.rs_ag = os.environ.get('VLMO_DP_COLLECTIVE', 'all_reduce') == 'rs_ag'
+        self.comm_mode = comm or os.environ.get('VLMO_DP_COMM', 'torch')
+        if self.comm_mode not in ('torch', 'native'):
+            raise ValueError(f"comm must be 'torch' or 'native', got {self.comm_mode!r}")
+        self.native = None
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
         self.rank = dist.get_rank(self.pg)
@@ -135,7 +136,25 @@ class GradReducer:
             for i, p in enumerate(b.params):
                 self._of[p] = (b, i)
                 p.register_post_accumulate_grad_hook(self._hook)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.comm_stream = None
+        if self.on_gpu:
+            # a stream that really runs beside the caller's stream and the weight-gradient stream (engine.pick_stream)
+            from . import engine
+            dev = self.device
+            with torch.cuda.device(dev):
+                busy = [torch.cuda.current_stream(dev), engine._side_stream(dev)]
+                make = lambda: torch.cuda.Stream(device=dev)
+                self.comm_stream = engine.pick_stream(dev, make, busy) if engine.PROBE_STREAMS else make()
+        if self.comm_mode == 'native':
+            if not self.on_gpu:
+                raise RuntimeError("comm='native' is the RCCL communicator of the HIP library: GPU parameters only")
+            from . import hip
+            # bootstrap over the existing process group: rank 0 draws the id, everybody joins
+            uid = [hip.comm_unique_id() if self.rank == 0 else None]
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not dist.group.WORLD else 0
+            dist.broadcast_object_list(uid, src=src, group=self.pg)
+            with torch.cuda.device(self.device):
+                self.native = hip.comm_init(uid[0], self.rank, self.world)
         self._armed = False
         self.sinks = {}
         self.arenas = {}
@@ -155,6 +174,72 @@ class GradReducer:
         self.arenas.clear()
         self._sink_params.clear()
         self._armed = False
+        if self.native is not None:
+            from . import hip
+            torch.cuda.synchronize(self.device)
+            hip.comm_destroy(self.native)
+            self.native = None
+
+    # ------------------------------------------------------------ collectives
+    # All of them are issued inside `with torch.cuda.stream(self.comm_stream)` on the GPU; the returned handle's
+    # wait() orders that stream after the collective (torch) or is a no-op (native: same stream already).
+    def _c_all_reduce(self, t):
+        """Sum of a flat bucket over the ranks, in place.  rs_ag (VLMO_DP_COLLECTIVE=rs_ag): the same result as a
+        reduce-scatter + all-gather pair on the bucket in place (what a ring all-reduce is made of, issued as the two
+        collectives RCCL schedules over all xGMI links) -- an A/B switch for the first multi-GPU run."""
+        split = self.rs_ag and self.world > 1 and t.numel() % self.world == 0
+        n = t.numel() // self.world
+        mine = t[self.rank * n:(self.rank + 1) * n] if split else None
+        if self.native is not None:
+            from . import hip
+            if split:
+                hip.comm_reduce_scatter(self.native, mine, t)
+                hip.comm_all_gather(self.native, t, mine)
+            else:
+                hip.comm_all_reduce(self.native, t)
+            return _Enqueued()
+        if split:
+            dist.reduce_scatter_tensor(mine, t, group=self.pg)
+            return dist.all_gather_into_tensor(t, mine, group=self.pg, async_op=True)
+        return dist.all_reduce(t, group=self.pg, async_op=True)
+
+    def _c_reduce_scatter(self, out, src):
+        if self.native is not None:
+            from . import hip
+            hip.comm_reduce_scatter(self.native, out, src)
+            return _Enqueued()
+        return dist.reduce_scatter_tensor(out, src, group=self.pg, async_op=True)
+
+    def all_gather(self, out, src):
+        """out [world * n] <- every rank's src [n] (src may be out's own slice), on the CURRENT stream."""
+        if self.native is not None:
+            from . import hip
+            hip.comm_all_gather(self.native, out, src)
+        else:
+            dist.all_gather_into_tensor(out, src, group=self.pg)
+
+    def all_reduce_now(self, t):
+        """in-place sum on the CURRENT stream (small tensors: the squared gradient norm of the sharded step)."""
+        if self.native is not None:
+            from . import hip
+            hip.comm_all_reduce(self.native, t)
+        else:
+            dist.all_reduce(t, group=self.pg)
+
+    def _pack(self, flat, comm):
+        """comm (bf16) = flat (fp32) / world in ONE pass on the current stream."""
+        if self.on_gpu and comm.dtype == torch.bfloat16 and flat.data_ptr() % 16 == 0 and comm.data_ptr() % 16 == 0:
+            from . import hip
+            hip.grad_pack(flat, comm, 1.0 / self.world)
+        else:
+            torch.mul(flat, 1.0 / self.world, out=comm)
+
+    def _unpack_into(self, comm, flat):
+        if self.on_gpu and comm.dtype == torch.bfloat16 and flat.data_ptr() % 16 == 0 and comm.data_ptr() % 16 == 0:
+            from . import hip
+            hip.grad_unpack(comm, flat)
+        else:
+            flat.copy_(comm)
 
     # ------------------------------------------------------------------ setup
     def sync_params(self, module):
@@ -314,13 +399,13 @@ class GradReducer:
         self._comm_wait()
         with torch.cuda.stream(self.comm_stream):
             if comm.data_ptr() != flat.data_ptr():
-                torch.mul(flat, 1.0 / self.world, out=comm)
+                self._pack(flat, comm)
             else:
                 flat.mul_(1.0 / self.world)
-            work = _all_reduce(comm, self.pg, self.world, self.rs_ag)
+            work = self._c_all_reduce(comm)
             work.wait()
             if comm.data_ptr() != flat.data_ptr():
-                flat.copy_(comm)
+                self._unpack_into(comm, flat)
         for sb in sbs:
             sb.work, sb.unpacked, sb.reduced, sb.has_grad = work, True, True, True
 
@@ -337,7 +422,7 @@ class GradReducer:
         with ctxm:
             src = sb.comm
             if sb.comm is not sb.flat:
-                torch.mul(sb.flat, 1.0 / self.world, out=sb.comm)   # ONE pass: 1/world scaling + fp32 -> bf16 pack
+                self._pack(sb.flat, sb.comm)        # ONE pass: 1/world scaling + fp32 -> bf16 pack
             elif self.reduce_scatter:
                 # fp32 communication + gradient partition: the reduce-scatter writes only the shard, so `flat` stays the
                 # LOCAL accumulator that the next micro-step of a gradient-accumulation window adds to -- it must never
@@ -354,9 +439,9 @@ class GradReducer:
                     sb.shard_comm = torch.empty(n, dtype=sb.comm.dtype, device=self.device)
                     sb.shard32 = sb.shard_comm if sb.comm.dtype == torch.float32 else torch.empty(
                         n, dtype=torch.float32, device=self.device)
-                sb.work = dist.reduce_scatter_tensor(sb.shard_comm, src, group=self.pg, async_op=True)
+                sb.work = self._c_reduce_scatter(sb.shard_comm, src)
             else:
-                sb.work = _all_reduce(sb.comm, self.pg, self.world, self.rs_ag)
+                sb.work = self._c_all_reduce(sb.comm)
             if self.on_gpu:
                 # the unpack follows its collective on the communication stream (work.wait() orders this stream
                 # after the collective, it does not block the host): it overlaps the rest of the backward pass
@@ -367,10 +452,10 @@ class GradReducer:
     def _unpack_sink(self, sb):
         if self.reduce_scatter:
             if sb.shard32 is not sb.shard_comm:
-                sb.shard32.copy_(sb.shard_comm)
+                self._unpack_into(sb.shard_comm, sb.shard32)
             sb.shard = sb.shard32
         elif sb.comm is not sb.flat:
-            sb.flat.copy_(sb.comm)               # ONE pass: bf16 -> fp32 unpack (already averaged)
+            self._unpack_into(sb.comm, sb.flat)  # ONE pass: bf16 -> fp32 unpack (already averaged)
         sb.unpacked = True
 
     def _hook(self, p):
@@ -411,9 +496,9 @@ class GradReducer:
                     b.shard_comm = torch.empty(n, dtype=b.comm.dtype, device=self.device)
                     b.shard32 = b.shard_comm if b.comm.dtype == torch.float32 else torch.empty(
                         n, dtype=torch.float32, device=self.device)
-                b.work = dist.reduce_scatter_tensor(b.shard_comm, b.comm, group=self.pg, async_op=True)
+                b.work = self._c_reduce_scatter(b.shard_comm, b.comm)
             else:
-                b.work = _all_reduce(b.comm, self.pg, self.world, self.rs_ag)
+                b.work = self._c_all_reduce(b.comm)
             if self.on_gpu:
                 b.work.wait()           # orders the communication stream after the collective (no host block)
                 self._unpack(b)
@@ -422,10 +507,10 @@ class GradReducer:
     def _unpack(self, b):
         if self.reduce_scatter:
             if b.shard32 is not b.shard_comm:
-                b.shard32.copy_(b.shard_comm)
+                self._unpack_into(b.shard_comm, b.shard32)
             b.shard = b.shard32
         elif b.comm is not b.flat:
-            b.flat.copy_(b.comm)                     # bf16 -> fp32 unpack (already averaged)
+            self._unpack_into(b.comm, b.flat)        # bf16 -> fp32 unpack (already averaged)
         b.unpacked = True
 
     def finish(self, accumulate=False):

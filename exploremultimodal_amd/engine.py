@@ -22,6 +22,7 @@ GRAD_SINK = None         # set by dp.GradReducer: block gradients are accumulate
 import os as _os
 OVERLAP_WGRAD = _os.environ.get('VLMO_OVERLAP_WGRAD', '1') != '0'   # weight-gradient GEMMs + bias column sums on a side stream
 SIDE_MODE = _os.environ.get('VLMO_SIDE_STREAM', 'low')
+PROBE_STREAMS = _os.environ.get('VLMO_PROBE_STREAMS', '1') != '0'
 MERGE_SEPARATE_ATTENTION = _os.environ.get('VLMO_MERGE_ATTN', '1') != '0'
 DEFAULT_TILE = -1        # GEMM tile: -1 = chosen per shape by the library (see vlmo_gemm_nt)
 
@@ -165,14 +166,61 @@ def _side_stream(dev):
     'low' (default) | 'normal' | 'cumask:<hex words, comma separated>' (measurement aid)."""
     s = _SIDE.get(dev)
     if s is None:
-        with torch.cuda.device(dev):
+        def make():
             if SIDE_MODE.startswith('cumask:'):
                 raw = hip.side_stream_create(False, [int(w, 16) for w in SIDE_MODE[7:].split(',')])
             else:
                 raw = hip.side_stream_create(SIDE_MODE != 'normal')
-        s = torch.cuda.ExternalStream(raw, device=dev)
+            return torch.cuda.ExternalStream(raw, device=dev)
+        with torch.cuda.device(dev):
+            s = pick_stream(dev, make, [torch.cuda.current_stream(dev)]) if PROBE_STREAMS else make()
         _SIDE[dev] = s
     return s
+
+
+def _queued_behind(dev, busy, cand):
+    """True when work on stream `cand` waits for kernels on stream `busy` (the two share a hardware queue, or their
+    queues share a command-processor pipe): a long memory-bound kernel sequence goes to `busy`, a one-element kernel
+    to `cand` right behind it; sharing shows as the small kernel finishing only when the long ones have."""
+    scratch = torch.empty(1 << 26, device=dev)                 # 256 MB: one pass ~0.1 ms, far more than one dispatch round
+    tiny = torch.empty(64, device=dev)
+    votes = 0
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0, t1, t2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(busy):
+            scratch.zero_()                                     # the timer starts once `busy` is running
+            t0.record()
+            for _ in range(6):
+                scratch.mul_(1.0)
+            t1.record()
+        with torch.cuda.stream(cand):
+            tiny.zero_()
+            t2.record()
+        torch.cuda.synchronize(dev)
+        votes += t0.elapsed_time(t2) > 0.5 * t0.elapsed_time(t1)
+    return votes == 2
+
+
+def pick_stream(dev, make, against, tries=8):
+    """A stream from make() whose work does not queue behind any stream of `against`.  HIP hands streams their
+    hardware queues round-robin and the queues are spread over the command processor's pipes by creation order, so
+    whether two streams can run side by side depends on what else (RCCL, the framework) created streams before:
+    measured here, a step with the reducer took 22.9 instead of 16.5 ms when the communication stream's queue shared the
+    main stream's pipe (rocprofv3: every kernel on it started ~50 us late), and one stream in four of a fresh batch
+    finishes a one-element kernel 1.4 ms late behind a busy main stream (tools/pipe_probe.py).  Probing is the only
+    portable way to know.  Falls back to the first candidate when every one collides."""
+    first = None
+    for _ in range(tries):
+        s = make()
+        first = first or s
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=dev)                          # binds the hardware queue
+        if not any(_queued_behind(dev, a, s) for a in against):
+            return s
+    import warnings
+    warnings.warn('no stream found that runs beside the main stream: side-stream work will serialise')
+    return first
 
 
 class _Fork:

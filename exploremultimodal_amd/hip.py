@@ -118,6 +118,15 @@ _SIGS = {
     'vlmo_side_stream_create': [_i32, ctypes.POINTER(ctypes.c_uint32), _i32, ctypes.POINTER(ctypes.c_void_p)],
     'vlmo_profile_stop': [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                           ctypes.POINTER(ctypes.c_int64)],
+    'vlmo_comm_available': [],
+    'vlmo_comm_unique_id': [_vp],
+    'vlmo_comm_init': [ctypes.POINTER(ctypes.c_void_p), _vp, _i32, _i32],
+    'vlmo_comm_destroy': [_vp],
+    'vlmo_comm_all_reduce': [_vp, _vp, _vp, _i64, _i32, _vp],
+    'vlmo_comm_reduce_scatter': [_vp, _vp, _vp, _i64, _i32, _vp],
+    'vlmo_comm_all_gather': [_vp, _vp, _vp, _i64, _i32, _vp],
+    'vlmo_grad_pack': [_vp, _vp, _i64, _f32, _vp],
+    'vlmo_grad_unpack': [_vp, _vp, _i64, _vp],
 }
 
 _lib = None
@@ -415,6 +424,65 @@ def stream_wait_event(stream, ev):
     """stream: torch stream (or raw handle); ev: handle from event_create()."""
     raw = stream.cuda_stream if hasattr(stream, 'cuda_stream') else stream
     _check(lib().vlmo_stream_wait_event(raw, ev), 'vlmo_stream_wait_event')
+
+
+# ---- gradient exchange (include/vlmo_hip.h: vlmo_comm_*) -------------------------------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_available():
+    return bool(lib().vlmo_comm_available())
+
+
+def comm_unique_id():
+    """128 opaque bytes; rank 0 creates them, every rank passes the same ones to comm_init."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().vlmo_comm_unique_id(buf), 'vlmo_comm_unique_id')
+    return buf.raw
+
+
+def comm_init(uid, rank, world):
+    if len(uid) != COMM_ID_BYTES:
+        raise ValueError(f'communicator id must be {COMM_ID_BYTES} bytes')
+    out = ctypes.c_void_p()
+    _check(lib().vlmo_comm_init(ctypes.byref(out), ctypes.c_char_p(bytes(uid)), rank, world), 'vlmo_comm_init')
+    return out.value
+
+
+def comm_destroy(comm):
+    _check(lib().vlmo_comm_destroy(comm), 'vlmo_comm_destroy')
+
+
+def comm_all_reduce(comm, t, stream=None):
+    """in-place sum over the ranks, enqueued on `stream` (default: the current stream)."""
+    raw = _stream() if stream is None else stream.cuda_stream
+    _check(lib().vlmo_comm_all_reduce(comm, _p(t), _p(t), t.numel(), _dt(t), raw), 'vlmo_comm_all_reduce')
+
+
+def comm_reduce_scatter(comm, out, src, stream=None):
+    assert src.numel() % out.numel() == 0 and src.dtype == out.dtype
+    raw = _stream() if stream is None else stream.cuda_stream
+    _check(lib().vlmo_comm_reduce_scatter(comm, _p(src), _p(out), out.numel(), _dt(out), raw),
+           'vlmo_comm_reduce_scatter')
+
+
+def comm_all_gather(comm, out, src, stream=None):
+    assert out.numel() % src.numel() == 0 and src.dtype == out.dtype
+    raw = _stream() if stream is None else stream.cuda_stream
+    _check(lib().vlmo_comm_all_gather(comm, _p(src), _p(out), src.numel(), _dt(src), raw), 'vlmo_comm_all_gather')
+
+
+def grad_pack(src, dst, scale, stream=None):
+    """dst (bf16) = src (fp32) * scale, one pass."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    raw = _stream() if stream is None else stream.cuda_stream
+    _check(lib().vlmo_grad_pack(_p(src), _p(dst), src.numel(), float(scale), raw), 'vlmo_grad_pack')
+
+
+def grad_unpack(src, dst, stream=None):
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.numel() == dst.numel()
+    raw = _stream() if stream is None else stream.cuda_stream
+    _check(lib().vlmo_grad_unpack(_p(src), _p(dst), src.numel(), raw), 'vlmo_grad_unpack')
 
 
 def stack_fwd(sdesc):

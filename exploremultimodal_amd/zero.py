@@ -213,7 +213,7 @@ class ZeroAdam:
         if clip_grad is not None:
             sq = self._local_sqnorm(tab).reshape(1).clone()
             if red.world > 1:
-                dist.all_reduce(sq, group=red.pg)
+                red.all_reduce_now(sq)
             norm = sq.sqrt()
             bad = ~torch.isfinite(norm)
             coef = torch.clamp(clip_grad / (norm + 1e-6), max=1.0) if clip_grad > 0 else torch.ones_like(norm)
@@ -251,7 +251,7 @@ class ZeroAdam:
             for pt in self.parts:       # the same buckets on every rank: routing is static, prepare() walks the same graph
                 if getattr(pt.bucket, 'shard32', None) is None or not getattr(pt.bucket, 'has_grad', False):
                     continue
-                dist.all_gather_into_tensor(pt.pflat, pt.pflat[pt.lo:pt.hi], group=red.pg)
+                red.all_gather(pt.pflat, pt.pflat[pt.lo:pt.hi])
         # the parameters changed behind autograd's back: invalidate the engine's bf16 weight shadows
         torch.autograd.graph.increment_version([p for pt in self.parts for p, _, _ in pt.entries])
         self.last_ctl = ctl

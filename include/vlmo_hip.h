@@ -332,6 +332,28 @@ int vlmo_event_create(void** out);
 int vlmo_event_destroy(void* ev);
 int vlmo_stream_wait_event(hipStream_t stream, void* ev);
 
+/* ---- gradient exchange (replaces torch DDP / DeepSpeed ZeRO-2 over NCCL, train/pretrain/multimodal.py:61-95,
+ * conf/ds_stage/l2.yaml) ----
+ * RCCL over xGMI, one communicator per process, collectives enqueued on the caller's stream, sum reduction.  RCCL is
+ * resolved at run time (the copy already in the process, else librccl.so); without it every entry returns -1.
+ * Bootstrap: rank 0 calls vlmo_comm_unique_id and hands the 128 bytes to the other ranks by any means (the Python host
+ * uses the torch.distributed store); every rank then calls vlmo_comm_init (blocks until all ranks arrived). */
+#define VLMO_COMM_ID_BYTES 128
+int vlmo_comm_available(void);
+int vlmo_comm_unique_id(void* id128);
+int vlmo_comm_init(void** comm, const void* id128, int rank, int world);
+int vlmo_comm_destroy(void* comm);
+int vlmo_comm_all_reduce(void* comm, const void* send, void* recv, int64_t count, int dtype, hipStream_t stream);
+/* send [world * recv_count] -> recv [recv_count] = this rank's slice of the sum (ZeRO-2 gradient partition) */
+int vlmo_comm_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype,
+                             hipStream_t stream);
+/* send [send_count] -> recv [world * send_count]; send may be recv + rank * send_count (in place) */
+int vlmo_comm_all_gather(void* comm, const void* send, void* recv, int64_t send_count, int dtype,
+                         hipStream_t stream);
+/* the reducer's two passes over a gradient arena: dst bf16 = src * scale (1 / world), and back.  16-B aligned. */
+int vlmo_grad_pack(const float* src, void* dst_bf16, int64_t n, float scale, hipStream_t stream);
+int vlmo_grad_unpack(const void* src_bf16, float* dst, int64_t n, hipStream_t stream);
+
 /* ---- dall_e dVAE encoder (dall_e/encoder.py:49-133), fp16 NHWC activations [B*H*W, C] ---- */
 
 /* Conv2d, stride 1, same padding (kw-1)/2 (dall_e/utils.py:37-48) as implicit GEMM:

@@ -155,9 +155,11 @@ def test_training_mode_dropout_is_unbiased_and_seeded():
     assert (a - ref).abs().mean().item() < 0.5   # perturbed, not destroyed
 
 
-def test_grad_reducer_rccl_single_rank():
+@pytest.mark.parametrize('comm', ['torch', 'native'])
+def test_grad_reducer_rccl_single_rank(comm):
     """The RCCL path (side stream, bf16 comm buffers, hooks fired from the autograd thread) at world
-    size 1: averaged gradients == local gradients up to one bf16 rounding."""
+    size 1: averaged gradients == local gradients up to one bf16 rounding.  comm='native': the collectives go through
+    the library's own communicator (vlmo_comm_*) instead of torch.distributed."""
     import torch.distributed as dist
     from exploremultimodal_amd.dp import GradReducer
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
@@ -166,7 +168,8 @@ def test_grad_reducer_rccl_single_rank():
     try:
         model, mc = build('mini')
         model.train()
-        red = GradReducer(model)
+        red = GradReducer(model, comm=comm)
+        assert (red.native is not None) == (comm == 'native')
         batch = synth.synth_batch(mc, 4, seed=3)
         kw = modes(mc, batch, 4)['vl']
         x, _ = model.forward_features(**kw)
