@@ -232,6 +232,186 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
     }
 }
 
+// ---- forward, one wave per query tile (sequences of <= 9 tiles = 288 tokens) ------------------------------------
+// The chunked kernel above gives a wave several query tiles in turn (7 tiles over 4 waves at 197 tokens: the last round
+// runs one wave short, each tile starts with an exposed global load of its Q rows) and carries 64 score registers per
+// chunk, i.e. two waves per SIMD.  Here a workgroup has one wave per query tile (right-sized: 7 waves at 197 tokens,
+// 2 at 64; waves past the sequence's last tile of a mixed launch leave after the staging barrier), the Q fragments are
+// loaded from global memory before the K / V images are staged, and the key tiles are walked one at a time:
+//   * the accumulator of the S^T MFMAs starts at the key bias (0 / -inf), so masking costs no vector instruction;
+//   * the running maximum is lazy: the accumulators are rescaled only when some row's maximum grew by more than 2^8
+//     since the last rescale (a wave-uniform branch, taken on the first tile and almost never again) -- exp2 arguments
+//     stay <= 8, the final division by the row sum cancels the stale reference exactly as in the eager form;
+//   * row sums are per half-wave partials, combined once at the end;
+//   * the S^T product of tile t + 1 is issued before the soft-max arithmetic of tile t, whose P^T V products run under the
+//     next tile's arithmetic: the matrix pipe works while the wave issues vector instructions.
+// ~110 registers: four waves per SIMD, two workgroups per CU at 197 tokens.
+__global__ __launch_bounds__(576) void attn_fwd1_kernel(const AttnArgs a, const int NPAD) {
+    const int IMG = NPAD * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kimg = smem;
+    char* Vimg = smem + IMG;
+    float* kbias = (float*)(smem + 2 * IMG);
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int bh = blockIdx.x, sidx = bh / a.heads, hd = bh % a.heads;
+    const int ld = 3 * a.d;
+    const int rowA = a.seg[4 * sidx + 0], lenA = a.seg[4 * sidx + 1], rowB = a.seg[4 * sidx + 2], lenB = a.seg[4 * sidx + 3];
+    const int N = lenA + lenB;
+    auto rowof = [&](int tok) {
+        tok = min(tok, N - 1);
+        return tok < lenA ? rowA + tok : rowB + (tok - lenA);
+    };
+    const int nq = (N + 31) >> 5;
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool active = w < nq;
+    const int qi = w * 32 + l31;
+    const int qrow = rowof(qi);
+    bf16x8 qf[4];
+    if (active) {
+        const bf16* qp = a.qkv + (size_t)qrow * ld + hd * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+    }
+    for (int ii = w; ii < nq * 4; ii += nw) {
+        const int chhi = lane >> 5, rowlo = (lane >> 2) & 7, pc = lane & 3;
+        const int row = ii * 8 + rowlo;
+        const int ch = chhi * 4 + (pc ^ ((row >> 2) & 3));
+        const size_t r = (size_t)rowof(row);
+        glds16(a.qkv + r * ld + a.d + hd * 64 + ch * 8, Kimg + ii * 1024);
+        glds16(a.qkv + r * ld + 2 * a.d + hd * 64 + ch * 8, Vimg + ii * 1024);
+    }
+    for (int i = threadIdx.x; i < NPAD; i += blockDim.x) {
+        const bool ok = (i < N) && (!a.keymask || a.keymask[rowof(i)] != 0);
+        kbias[i] = ok ? 0.f : -INFINITY;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+
+    // LDS addressing as in attn_bwd1_kernel: per-lane offsets once, tile bases as scalars / immediates
+    const int xq = (l31 >> 2) & 3;
+    const int rf0 = 1024 * (l31 >> 3) + 64 * (l31 & 7) + 16 * (h ^ xq);
+    const int rf1 = 1024 * (l31 >> 3) + 64 * (l31 & 7) + 16 * ((2 + h) ^ xq);
+    const int tg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int trl = 64 * (4 * h + tq) + 16 * ((2 * tg + (tp >> 1)) ^ h) + 8 * (tp & 1);
+    const int trh = 1024 + 64 * (4 * h + tq) + 16 * ((2 * tg + (tp >> 1)) ^ ((2 + h) & 3)) + 8 * (tp & 1);
+    auto rfrag = [&](const char* img_rb, int s) -> bf16x8 {
+        return *(const bf16x8*)(img_rb + 512 * (s >> 1) + ((s & 1) ? rf1 : rf0));
+    };
+    auto tfrag = [&](const char* img_rb, int dt) -> bf16x8 {
+        const bf16x4 lo = lds_tr4<bf16>(img_rb + 512 * dt + trl);
+        const bf16x4 hi = lds_tr4<bf16>(img_rb + 512 * dt + trh);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto other_half = [&](float v) -> float {       // the value lane ^ 32 holds (v_permlane32_swap: no LDS round trip)
+        const uint32_t u = __builtin_bit_cast(uint32_t, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __builtin_bit_cast(float, h ? r[0] : r[1]);
+    };
+    // S^T tile of key tile kt: accumulator = key bias of the rows this lane holds (8 (i >> 2) + 4 h + (i & 3))
+    auto s_tile = [&](int kt) -> f32x16 {
+        f32x16 acc;
+        const float* kb = kbias + kt * 32 + 4 * h;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *(const f32x4*)(kb + 8 * g4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g4 + e] = v[e];
+        }
+        const char* kimg = Kimg + 4096 * kt;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = Elem<bf16>::mfma(rfrag(kimg, s), qf[s], acc);
+        return acc;
+    };
+
+    const uint32_t akey = att_key(a.seed, bh);
+    const uint32_t rq = ((uint32_t)qi * 512u + 4u * h) * ATT_G + akey;
+    const float c2 = a.scale_log2e;
+    const float thr = 8.f / c2;             // lazy-rescale threshold in raw score units
+    float m_run = -INFINITY;                // reference maximum in raw score units
+    f32x2 l2 = {0.f, 0.f};                  // this half-wave's partial row sum, two interleaved accumulators (v_pk_add_f32)
+    f32x16 O[2] = {zero16(), zero16()};
+    // soft-max + dropout of one S^T tile in place, then its P^T V products
+    auto consume = [&](f32x16& S, int kt) {
+        float mx = fmaxf(fmaxf(S[0], S[1]), S[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, S[i]), S[i + 1]);
+        mx = fmaxf(mx, S[15]);
+        mx = fmaxf(mx, other_half(mx));
+        if (__builtin_amdgcn_ballot_w64(mx - m_run > thr)) {
+            asm volatile("" ::: "memory");      // a real branch: hipcc otherwise if-converts it into 17 packed multiplies per tile
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = (m_run == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l2 *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            m_run = m_new;
+        }
+        const float msub = (m_run == -INFINITY) ? 0.f : -m_run * c2;
+        const f32x2 c2v = {c2, c2}, msv = {msub, msub};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 t = f32x2{S[i], S[i + 1]} * c2v + msv;      // v_pk_fma_f32
+            const f32x2 pr = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            l2 += pr;
+            S[i] = pr[0];
+            S[i + 1] = pr[1];
+        }
+        if (a.drop_thresh) {
+            const uint32_t rk = rq + (uint32_t)(kt * 32) * ATT_G;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (att_mix(rk + (uint32_t)(8 * g4 + e) * ATT_G) < a.drop_cmp) S[4 * g4 + e] = 0.f;
+        }
+        const char* vimg = Vimg + 4096 * kt;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16)S[8 * s2 + j];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) O[dt] = Elem<bf16>::mfma(tfrag(vimg + 2048 * s2, dt), pf, O[dt]);
+        }
+    };
+    // two tiles per trip, the S^T buffers alternate (no register copies): the product of the next tile is in flight
+    // while the current one is consumed
+    f32x16 S0 = s_tile(0), S1;
+    for (int kt = 0; kt < nq; kt += 2) {
+        if (kt + 1 < nq) S1 = s_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(S0, kt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nq) {
+            if (kt + 2 < nq) S0 = s_tile(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(S1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float l_run = l2[0] + l2[1];
+    const float l_tot = l_run + other_half(l_run);
+    if (qi < N) {
+        const float inv = a.inv_keep / l_tot;
+        bf16* op = a.out + (size_t)qrow * a.d + hd * 64 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 o = {(bf16)(O[dt][4 * g4 + 0] * inv), (bf16)(O[dt][4 * g4 + 1] * inv),
+                            (bf16)(O[dt][4 * g4 + 2] * inv), (bf16)(O[dt][4 * g4 + 3] * inv)};
+                *(bf16x4*)(op + dt * 32 + 8 * g4) = o;
+            }
+        if (h == 0 && a.lse) a.lse[(size_t)bh * a.lse_stride + qi] = (m_run * c2 + log2f(l_tot)) * LN2;
+    }
+}
+
 // ------------------------------------------------------------------ backward
 // Column sums for the qkv-bias gradient (vlmo.py:71-75: q_bias / v_bias; the k third is a constant zero): t[dt][r] holds
 // feature dt * 32 + (r & 3) + 8 (r >> 2) + 4 h of the token on lane & 31.  Sum over the wave's 32 tokens (butterfly inside
@@ -507,7 +687,7 @@ __device__ __forceinline__ int slot_off(int k, int q) {
 // 168-register budget against 96 accumulator registers + V fragments + the S / dP tiles -- hipcc spills 160-330
 // registers there and the N = 261 backward takes 200-450 us instead of 120.  Sequences of 257-288 tokens (the fused
 // layers at T = 64) therefore stay on the two-phase kernel above.
-// Measured (MI355X, B = 64, 12 heads, dropout 0.1; tools/attn_bench.py): N = 197 81 us (two-phase 94), N = 64 16 us (25).
+// Measured (MI355X, B = 64, 12 heads, dropout 0.1; tools/attn_bench.py): N = 197 78 us (two-phase 94), N = 64 16 us (25).
 // Per workgroup at N = 197 (s_memrealtime stamps): 7 us before the first product (165 KB through one CU's vector
 // memory path at ~25 GB/s: images + V fragments + the ctx / dctx rows for delta), 13 us in the loop (1.9 us per step:
 // the two waves of a SIMD spend it in ~180 + ~180 soft-max / dropout instructions, SQ_ACTIVE_INST_VALU is what bounds
@@ -843,6 +1023,16 @@ int launch_fwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblocks), dim3(256), LDS, st, a, nt * 32);
     return 0;
 }
+int launch_fwd1(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
+    const int LDS = nt * 32 * 256 + nt * 32 * 4;
+    int& max_set = lds_limit_set(3);
+    if (LDS > max_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        max_set = LDS;
+    }
+    hipLaunchKernelGGL(attn_fwd1_kernel, dim3(nblocks), dim3(nt * 64), LDS, st, a, nt * 32);
+    return 0;
+}
 int launch_bwd(const AttnArgs& a, int nt, int nblocks, hipStream_t st) {
     const int LDS = nt * 32 * 512 + nt * 32 * 16 + 32 + 512;
     int& max_set = lds_limit_set(1);
@@ -898,7 +1088,12 @@ extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, c
     a.inv_keep = drop_thresh ? inv_keep : 1.f;
     a.seed = seed;
     const int nt = (max_len + 31) / 32, nb = num_seq * heads;
-    launch_fwd(a, nt, nb, stream);
+    static const bool chunked = [] {
+        const char* e = getenv("VLMO_ATTN_FWD");
+        return e && !strcmp(e, "chunked");
+    }();
+    if (nt <= 9 && !chunked) launch_fwd1(a, nt, nb, stream);
+    else launch_fwd(a, nt, nb, stream);
     VLMO_CHECK_LAUNCH("vlmo_attn_fwd");
     return 0;
 }
