@@ -419,9 +419,6 @@ __global__ __launch_bounds__(576) void attn_fwd1_kernel(const AttnArgs a, const 
 // inclusive DPP scan over each 32-lane half (gfx9 row_shr / row_bcast15 sequence): lanes 31 and 63 end up with their
 // half's total.  Six v_add_f32_dpp; the same sum through __shfl_xor is five ds_bpermute round trips per register and
 // made the two reductions of a wave cost more than the 51 MB re-read of dqkv they replace.
-template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
-}
 __device__ __forceinline__ float half_wave_total(float v) {
     float s_ = v + dpp_mov<0x111, 0xf, 0xf>(v);         // row_shr:1 (lanes without a source read 0)
     s_ += dpp_mov<0x112, 0xf, 0xf>(v);                  // row_shr:2

@@ -176,10 +176,22 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return norm_cdf_from(x, e) + x * 0.39894228040143268f * e;
 }
 
+// v of the lane CTRL selects, 0 where that lane does not exist or the row / bank mask excludes the destination
+template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// Sum over the 64 lanes, the same value in every lane.  All lanes must be active.  A DPP scan (gfx9 row_shr / row_bcast:
+// seven dependent vector adds, ~60 cycles) + one v_readlane; the butterfly through __shfl_xor is six ds_bpermute round
+// trips (~700 cycles), which is what a LayerNorm row waited for twice when the kernel has one or two waves per SIMD.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    float s = v + dpp_mov<0x111, 0xf, 0xf>(v);          // row_shr:1
+    s += dpp_mov<0x112, 0xf, 0xf>(v);                   // row_shr:2
+    s += dpp_mov<0x113, 0xf, 0xf>(v);                   // row_shr:3  -> sums of 4
+    s += dpp_mov<0x114, 0xf, 0xe>(s);                   // row_shr:4, banks 1-3 -> sums of 8
+    s += dpp_mov<0x118, 0xf, 0xc>(s);                   // row_shr:8, banks 2-3 -> lane 15 of a row = the row's total
+    s += dpp_mov<0x142, 0xa, 0xf>(s);                   // row_bcast15 into rows 1 and 3
+    s += dpp_mov<0x143, 0xc, 0xf>(s);                   // row_bcast31 into rows 2 and 3 -> lane 63 = the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
