@@ -35,6 +35,12 @@ struct GemmNT {
     int cH, cW, cCin, ckw;
     const void* zero;
     int group_m;     // L2 tile swizzle: row-tiles per group
+    // two-segment A (vlmo_gemm_nt_2src): columns [0, k1) of the reduction come from A, [k1, K) from A2 (own leading
+    // dimension); the partial sum of the first segment is multiplied by seg_scale before the second one is added.
+    // k1 == 0: single source.
+    const void* A2;
+    int lda2, k1;
+    float seg_scale;
 };
 
 // Up to 4 problems with the same N, K, leading dimensions and epilogue kind in ONE launch (the per-modality
@@ -310,6 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             pl.M = uniform_i(gq.M), pl.N = uniform_i(gq.N), pl.K = uniform_i(gq.K), pl.lda = uniform_i(gq.lda), pl.ldb = uniform_i(gq.ldb);
             pl.cH = uniform_i(gq.cH), pl.cW = uniform_i(gq.cW), pl.cCin = uniform_i(gq.cCin), pl.ckw = uniform_i(gq.ckw);
             pl.group_m = uniform_i(gq.group_m);
+            pl.A2 = uniform_ptr(gq.A2), pl.lda2 = uniform_i(gq.lda2), pl.k1 = uniform_i(gq.k1), pl.seg_scale = uniform_f(gq.seg_scale);
             pl.e.out = (void*)uniform_ptr(gq.e.out), pl.e.out2 = (void*)uniform_ptr(gq.e.out2);
             pl.e.bias = (const float*)uniform_ptr(gq.e.bias), pl.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
             pl.e.resid = (const float*)uniform_ptr(gq.e.resid), pl.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
@@ -347,6 +354,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                 glds16(src, s + (i * NW + wave) * 1024);
             }
         } else {
+            if (pp->k1 && kt * BK == pp->k1) {
+                // second A segment: the same rows of A2, rebased so that `+ kt * BK` keeps addressing the reduction index
+                const T* A2_ = (const T*)pp->A2;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int rr = (i * NW + wave) * SRPI + lane / CPR;
+                    const int c = (lane % CPR) ^ nt_swz<BK>(rr);
+                    const int gr = min(m0 + rr, pp->M - 1);
+                    a_src[i] = A2_ + (size_t)gr * pp->lda2 + c * 8 - pp->k1;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) glds16(a_src[i] + kt * BK, s + (i * NW + wave) * 1024);
         }
@@ -383,6 +401,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                 for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
     };
     const GemmNT& p = *pp;
+    // first K-tile of the second A segment: the first segment's partial sum takes its scale (EncoderBlock tail:
+    // post_gain * res_path + id_path as ONE reduction over [conv_3 output | block input])
+    auto seg_boundary = [&](int kt) {
+        if constexpr (!CONV) {
+            if (pp->k1 && kt * BK == pp->k1 && pp->seg_scale != 1.f) {
+                const float sc = pp->seg_scale;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[i][j][k] *= sc;
+            }
+        }
+    };
     stage(0, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -434,6 +467,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
         for (int kt = 0; kt < nk; ++kt) {
             const char* cur = smem + (kt & 1) * STAGE;
             const bool more = kt + 1 < nk;
+            seg_boundary(kt);
             read_half(cur, 0);
             bar();
             if (more) stage((kt + 1) & 1, kt + 1);
@@ -454,6 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            seg_boundary(kt);
             compute(smem + (kt & 1) * STAGE);
         }
     }
@@ -1141,7 +1176,19 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     if (int rc = check_nt(epi, A, lda, B, ldb, M, N, K, e)) return rc;
     GemmNTGroups gp{};
     gp.ngroups = 1;
-    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_default()};
+    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_default(), nullptr, 0, 0, 1.f};
+    return run_nt(epi, dtype, tile, gp, stream);
+}
+
+extern "C" int vlmo_gemm_nt_2src(int epi, int dtype, int tile, const void* A, int lda, int k1, float seg_scale,
+                                 const void* A2, int lda2, const void* B, int ldb, int M, int N, int K,
+                                 const VlmoEpilogue* e, hipStream_t stream) {
+    VLMO_CHECK_ARG(A2 && k1 > 0 && k1 < K && k1 % 64 == 0, "vlmo_gemm_nt_2src: need 0 < k1 < K, k1 %% 64 == 0 (k1=%d, K=%d)", k1, K);
+    VLMO_CHECK_ARG(lda % 8 == 0 && lda >= k1 && lda2 % 8 == 0 && lda2 >= K - k1, "vlmo_gemm_nt_2src: bad lda/lda2 %d/%d", lda, lda2);
+    if (int rc = check_nt(epi, A, K > lda ? K : lda, B, ldb, M, N, K, e)) return rc;
+    GemmNTGroups gp{};
+    gp.ngroups = 1;
+    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_default(), A2, lda2, k1, seg_scale};
     return run_nt(epi, dtype, tile, gp, stream);
 }
 
@@ -1159,7 +1206,7 @@ extern "C" int vlmo_gemm_nt_grouped(int epi, int dtype, int tile, int ngroups, c
     gp.ngroups = ngroups;
     for (int q = 0; q < ngroups; ++q) {
         if (int rc = check_nt(epi, A[q], lda, B[q], ldb, M[q], N, K, &e[q])) return rc;
-        gp.g[q] = GemmNT{A[q], B[q], M[q], N, K, lda, ldb, e[q], 0, 0, 0, 0, nullptr, group_m_default()};
+        gp.g[q] = GemmNT{A[q], B[q], M[q], N, K, lda, ldb, e[q], 0, 0, 0, 0, nullptr, group_m_default(), nullptr, 0, 0, 1.f};
     }
     return run_nt(epi, dtype, tile, gp, stream);
 }
@@ -1371,7 +1418,7 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     const int K = kw * kw * Cin;
     GemmNTGroups p{};
     p.ngroups = 1;
-    p.g[0] = GemmNT{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8};
+    p.g[0] = GemmNT{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8, nullptr, 0, 0, 1.f};
     ProfScope prof(32 + epi, 2.0 * B * H * W * Cout * K, stream);
     // <= 64 output channels (the bottleneck convolutions of the dVAE's first group, 112 x 112 x 64): a 256 x 64 tile --
     // with the 128-wide tile half of every MFMA and half of the weight staging multiplied padding

@@ -93,6 +93,18 @@ class EncoderBlock(nn.Module):
             ('relu_2', nn.ReLU()), ('conv_2', mk(self.n_hid, self.n_hid, 3)),
             ('relu_3', nn.ReLU()), ('conv_3', mk(self.n_hid, self.n_hid, 3)),
             ('relu_4', nn.ReLU()), ('conv_4', mk(self.n_hid, n_out, 1))]))
+        self._tail = None
+
+    def tail_shadow(self):
+        """Convolutional id_path: [conv_4.w | id_path.w] as ONE fp16 matrix [n_out, n_hid + n_in] and the combined bias
+        post_gain * conv_4.b + id_path.b, for the block tail as a single two-segment GEMM (encoder.py:45-46)."""
+        c4, idp = self.res_path.conv_4, self.id_path
+        ver = (c4.w._version, c4.w.data_ptr(), idp.w._version, idp.w.data_ptr(), c4.b._version, idp.b._version)
+        if getattr(self, '_tail', None) is None or self._tail[0] != ver:
+            w4, b4 = c4.shadow()
+            wi, bi = idp.shadow()
+            self._tail = (ver, torch.cat([w4, wi], 1).contiguous(), (self.post_gain * b4 + bi).contiguous())
+        return self._tail[1], self._tail[2]
 
 
 class Encoder(nn.Module):
@@ -170,17 +182,18 @@ class Encoder(nn.Module):
                     o = em(M, hid)
                     hip.conv2d_nhwc(hip.EPI_BIAS, t, B, h, w, c_in, 3, wq, hid, o, bias=bq, relu=True, relu_in=(ci == 1))
                     t, c_in = o, hid
-                if isinstance(blk.id_path, Conv2d):
-                    wi, bi_ = blk.id_path.shadow()
-                    idp = em(M, n_out)
-                    hip.gemm_nt(hip.EPI_BIAS, raw, wi, M, n_out, blk.n_in, idp, bias=bi_)
-                else:
-                    idp = raw
-                w4, b4 = blk.res_path.conv_4.shadow()
                 last = g == 4 and bi == self.n_blk_per_group     # the output convolution (a plain GEMM) reads relu(x)
                 raw2, rel2 = em(M, n_out), (em(M, n_out) if last else None)
-                hip.gemm_nt(hip.EPI_DUAL, t, w4, M, n_out, hid, raw2, out2=rel2, bias=b4, resid=idp,
-                            beta=blk.post_gain)
+                if isinstance(blk.id_path, Conv2d):
+                    # id_path(x) + post_gain * conv_4(t) as ONE reduction over [t | x] against [conv_4.w | id_path.w]: the
+                    # partial sum of the first segment takes post_gain in fp32 inside the kernel; no id-path tensor in HBM
+                    wc, bc = blk.tail_shadow()
+                    hip.gemm_nt(hip.EPI_DUAL, t, wc, M, n_out, hid + blk.n_in, raw2, out2=rel2, bias=bc, beta=1.0,
+                                A2=raw, k1=hid, seg_scale=blk.post_gain)
+                else:
+                    w4, b4 = blk.res_path.conv_4.shadow()
+                    hip.gemm_nt(hip.EPI_DUAL, t, w4, M, n_out, hid, raw2, out2=rel2, bias=b4, resid=raw,
+                                beta=blk.post_gain)
                 raw, rel = raw2, rel2
             if g < 4:
                 C2 = raw.shape[1]
@@ -194,21 +207,20 @@ class Encoder(nn.Module):
         """encoder.py:123-133 -> logits fp32 [B, vocab, H/8, W/8]."""
         rel, (B, h, w) = self._features(x)
         wo, bo = self.blocks.output.conv.shadow_split()
-        rel = torch.cat([rel, rel], 1)          # [x | x] against [w_hi | w_lo]
-        M = rel.shape[0]
+        M, C = rel.shape
         logits = torch.empty((M, self.vocab_size), dtype=torch.float32, device=x.device)
-        hip.gemm_nt(hip.EPI_F32, rel, wo, M, self.vocab_size, rel.shape[1], logits, bias=bo)
+        # [x | x] against [w_hi | w_lo]: the activations are the second segment's source too (no doubled copy in HBM)
+        hip.gemm_nt(hip.EPI_F32, rel, wo, M, self.vocab_size, 2 * C, logits, bias=bo, A2=rel, k1=C)
         return logits.view(B, h, w, self.vocab_size).permute(0, 3, 1, 2)
 
     def codebook_indices(self, x):
         """argmax(forward(x), dim=1) without materialising the logits -> int64 [B, H/8, W/8]."""
         rel, (B, h, w) = self._features(x)
         wo, bo = self.blocks.output.conv.shadow_split()
-        rel = torch.cat([rel, rel], 1)
-        M = rel.shape[0]
+        M, C = rel.shape
         nchunk = (self.vocab_size + 63) // 64
         part = torch.empty((M, nchunk, 2), dtype=torch.float32, device=x.device)
-        hip.gemm_nt(hip.EPI_ARGMAX, rel, wo, M, self.vocab_size, rel.shape[1], part, bias=bo, ldo=nchunk)
+        hip.gemm_nt(hip.EPI_ARGMAX, rel, wo, M, self.vocab_size, 2 * C, part, bias=bo, ldo=nchunk, A2=rel, k1=C)
         ids = torch.empty((M,), dtype=torch.int64, device=x.device)
         hip.argmax_reduce(part, nchunk, ids, M)
         return ids.view(B, h, w)

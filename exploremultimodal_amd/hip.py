@@ -118,6 +118,8 @@ _SIGS = {
     'vlmo_side_stream_create': [_i32, ctypes.POINTER(ctypes.c_uint32), _i32, ctypes.POINTER(ctypes.c_void_p)],
     'vlmo_profile_stop': [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                           ctypes.POINTER(ctypes.c_int64)],
+    'vlmo_gemm_nt_2src': [_i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _i32, _vp, _i32, _i32, _i32, _i32,
+                          ctypes.POINTER(Epilogue), _vp],
     'vlmo_comm_available': [],
     'vlmo_comm_unique_id': [_vp],
     'vlmo_comm_init': [ctypes.POINTER(ctypes.c_void_p), _vp, _i32, _i32],
@@ -207,12 +209,20 @@ def drop_params(p, training):
 
 def gemm_nt(epi, A, B, M, N, K, out, *, out2=None, bias=None, gamma=None, resid=None,
             row_scale=None, row_index=None, aux=None, ldo=None, ld2=None, relu=False, drop=(0, 1.0), seed=0,
-            beta=0.0, tile=-1, lda=None, ldb=None, colpart=None):
+            beta=0.0, tile=-1, lda=None, ldb=None, colpart=None, A2=None, k1=0, seg_scale=1.0):
+    """A2 / k1 / seg_scale: two-segment reduction (vlmo_gemm_nt_2src): columns [0, k1) of B meet A, [k1, K) meet A2, the
+    first segment's partial sum is multiplied by seg_scale."""
     e = Epilogue(_p(out), _p(out2), _p(bias), _p(gamma), _p(resid), _p(row_scale), _p(row_index), _p(aux),
                  ldo if ldo is not None else out.stride(0),
                  ld2 if ld2 is not None else (out2.stride(0) if out2 is not None else
                                               (aux.stride(0) if aux is not None else 0)),
                  int(relu), drop[0], drop[1], beta, seed & 0xFFFFFFFFFFFFFFFF, _p(colpart))
+    if A2 is not None:
+        rc = lib().vlmo_gemm_nt_2src(epi, _dt(A), tile, _p(A), lda if lda is not None else A.stride(0), k1,
+                                     float(seg_scale), _p(A2), A2.stride(0), _p(B),
+                                     ldb if ldb is not None else B.stride(0), M, N, K, ctypes.byref(e), _stream())
+        _check(rc, 'vlmo_gemm_nt_2src')
+        return
     rc = lib().vlmo_gemm_nt(epi, _dt(A), tile, _p(A), lda if lda is not None else A.stride(0),
                             _p(B), ldb if ldb is not None else B.stride(0), M, N, K,
                             ctypes.byref(e), _stream())

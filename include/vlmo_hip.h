@@ -87,6 +87,14 @@ int vlmo_abi_version(void);
  * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */
 int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const void* B, int ldb,
                  int M, int N, int K, const VlmoEpilogue* e, hipStream_t stream);
+/* C = epilogue((seg_scale * A[:, :k1] . B[:, :k1]^T) + A2[:, :K-k1] . B[:, k1:]^T): the reduction runs over two activation
+ * matrices with the same rows (own leading dimensions) against ONE weight matrix [N, K].  dall_e EncoderBlock tail
+ * (dall_e/encoder.py:45-46): id_path(x) + post_gain * res_path(x) with a convolutional id_path = one GEMM over
+ * [conv_3 output | x] against [conv_4.w | id_path.w]; output convolution with the fp32 weight split [w_hi | w_lo]:
+ * A2 = A (the activations are read twice instead of being concatenated in HBM).  k1 % 64 == 0. */
+int vlmo_gemm_nt_2src(int epi, int dtype, int tile, const void* A, int lda, int k1, float seg_scale, const void* A2,
+                      int lda2, const void* B, int ldb, int M, int N, int K, const VlmoEpilogue* e,
+                      hipStream_t stream);
 /* 1..4 problems C_g[M_g,N] = A_g[M_g,K] . B_g[N,K]^T with the same N, K, leading dimensions and epilogue kind
  * in ONE launch: the per-modality expert FFNs of a Block below the fusion layer (mlp['l'] on the text rows,
  * mlp['v'] on the image rows: vlmo.py:141-157, 195-196).  e[g] is group g's epilogue (its own outputs, bias,

@@ -156,3 +156,29 @@ def test_encoder_input_checks():
         Encoder(n_hid=32)
     with pytest.raises(NotImplementedError):
         create_d_vae(None, 'customized', 112, 'cpu')
+
+
+@pytest.mark.parametrize('M,N,k1,k2,dt,scale', [(300, 256, 128, 256, torch.float16, 1 / 64),      # EncoderBlock tail, small tiles
+                                                (1000, 512, 1024, 1024, torch.float16, 1.0),     # [x | x] . [w_hi | w_lo], 256x256 ping-pong
+                                                (257, 768, 64, 1536, torch.bfloat16, 0.5)])
+def test_gemm_nt_two_segments(M, N, k1, k2, dt, scale):
+    """vlmo_gemm_nt_2src: out = seg_scale * A W1^T + A2 W2^T + bias with W = [W1 | W2] one matrix; both sources with
+    their own leading dimension (A is a column slice of a wider buffer)."""
+    g = torch.Generator().manual_seed(M + N)
+    wide = torch.randn(M, k1 + 64, generator=g).to(dt).to(DEV)
+    A = wide[:, :k1]                      # lda = k1 + 64
+    A2 = torch.randn(M, k2, generator=g).to(dt).to(DEV)
+    W = (torch.randn(N, k1 + k2, generator=g) / (k1 + k2) ** 0.5).to(dt).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    ref = scale * (A.float() @ W[:, :k1].float().t()) + A2.float() @ W[:, k1:].float().t() + b
+    out = torch.empty(M, N, device=DEV, dtype=dt)
+    hip.gemm_nt(hip.EPI_BIAS, A, W, M, N, k1 + k2, out, bias=b, A2=A2, k1=k1, seg_scale=scale)
+    tol = 2 ** -8 if dt == torch.float16 else 2 ** -6
+    assert (out.float() - ref).abs().max().item() <= tol * (1 + ref.abs().max().item())
+    # same source twice (the output convolution's hi / lo weight halves)
+    if k1 == k2:
+        ref2 = A2.float() @ (W[:, :k1].float() + W[:, k1:].float()).t() + b
+        hip.gemm_nt(hip.EPI_BIAS, A2, W, M, N, 2 * k1, out, bias=b, A2=A2, k1=k1)
+        assert (out.float() - ref2).abs().max().item() <= tol * (1 + ref2.abs().max().item())
+    with pytest.raises(RuntimeError, match='k1'):
+        hip.gemm_nt(hip.EPI_BIAS, A, W, M, N, k1 + k2, out, bias=b, A2=A2, k1=k1 + 8)
