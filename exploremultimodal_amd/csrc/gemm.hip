@@ -1404,6 +1404,174 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
     return 0;
 }
 
+namespace {
+// ---- 3x3 convolution with <= 64 output channels (dall_e EncoderBlock bottleneck of the first group, encoder.py:21-29:
+// 112 x 112 x {256 -> 64, 64 -> 64}) ------------------------------------------------------------------------------
+// With 64 output channels the implicit GEMM is bound by the per-CU fill rate of its A operand: the generic kernel
+// stages the 256 input rows of a tile once per TAP (nine times per channel chunk: 40 KB per 16 MFMAs of a wave).  Here a
+// K-step is (dy, 32-channel half chunk): the rows [m0 - 8, m0 + 264) of image row y + dy are staged ONCE and the three
+// dx taps read them at row offsets -1 / 0 / +1 (the fragment of a lane whose pixel has no left / right neighbour is
+// zeroed in registers); the three taps' weights ride along: 29 KB per 24 MFMAs of a wave, 2.1x fewer staged bytes per
+// flop.  256 x 64 tile, 4 waves (64 pixels x 64 channels each), 2-deep LDS ring of 32-deep slices (59 KB: two
+// workgroups per CU, as the generic kernel -- a 64-deep ring with one workgroup per CU filled at 20 GB/s per CU and
+// lost on the K = 576 convolutions, whose three steps never fill the pipeline), f16.
+struct Conv3Args {
+    const f16* x;        // [B*H*W, Cin]
+    const f16* w;        // [Cout <= 64, 9 * Cin] tap-major, channel-minor
+    const f16* zero;     // >= 128 zero bytes
+    const float* bias;
+    f16* out;            // [B*H*W, ldo]
+    int M, H, W, Cin, Cout, ldo, relu;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3_n64_kernel(const Conv3Args a) {
+    constexpr int BM = 256, HALO = 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 64, B_BYTES = 3 * 64 * 64;
+    constexpr int STAGE = A_BYTES + B_BYTES, NAI = AROWS / 16, NBI = 3 * 64 / 16;      // 17 + 12 one-KiB pieces per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int HW = a.H * a.W, Cin = a.Cin, K = 9 * Cin;
+    const int cpt = Cin >> 5, nsteps = 3 * cpt;
+
+    // staging sources: piece ii = i * 4 + wave covers LDS rows ii * 16 .. + 15, lane -> (row, 16-byte chunk of 4)
+    const f16* a_src[5];
+    int a_y[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int rr = (i * 4 + wave) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ nt_swz<32>(rr);
+        const int pix = min(max(m0 - HALO + rr, 0), a.M - 1);
+        a_src[i] = a.x + (size_t)pix * Cin + c * 8;
+        a_y[i] = (pix % HW) / a.W;
+    }
+    const f16* b_src[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int rr = (i * 4 + wave) * 16 + (lane >> 2);      // 0..191 = tap dx * 64 + output channel
+        const int c = (lane & 3) ^ nt_swz<32>(rr);
+        const int n = min(rr & 63, a.Cout - 1);
+        b_src[i] = a.w + (size_t)n * K + (rr >> 6) * Cin + c * 8;
+    }
+    auto stage = [&](int buf, int s_) {
+        char* s = smem + buf * STAGE;
+        const int dyi = s_ / cpt, hc = s_ - dyi * cpt, dy = dyi - 1;
+        const int delta = dy * a.W * Cin + hc * 32;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i * 4 + wave < NAI) {
+                const bool in = (unsigned)(a_y[i] + dy) < (unsigned)a.H;
+                glds16(in ? a_src[i] + delta : a.zero, s + (i * 4 + wave) * 1024);
+            }
+        }
+        const int wofs = dyi * 3 * Cin + hc * 32;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16(b_src[i] + wofs, s + A_BYTES + (i * 4 + wave) * 1024);
+    };
+    static_assert(NBI == 12, "three weight pieces per wave");
+
+    const int l31 = lane & 31, h = lane >> 5;
+    // A fragment of tap dx, row block i: LDS row HALO + wave * 64 + i * 32 + l31 + dx (the swizzle key of a row does not
+    // change with + 32); B fragment: row dxi * 64 + j * 32 + l31
+    int a_off[3], a_swz[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int row = HALO + wave * 64 + l31 + (t - 1);
+        a_off[t] = row * 64;
+        a_swz[t] = nt_swz<32>(row);
+    }
+    const int b_off = A_BYTES + l31 * 64, b_swz = nt_swz<32>(l31);
+    bool edge_l[2], edge_r[2];      // the lane's pixel has no left / right neighbour in its image row
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int xx = (m0 + wave * 64 + i * 32 + l31) % a.W;
+        edge_l[i] = xx == 0;
+        edge_r[i] = xx == a.W - 1;
+    }
+    const bool relu_in = (a.relu & 2) != 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    stage(0, 0);
+    for (int s_ = 0; s_ < nsteps; ++s_) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s_ + 1 < nsteps) stage((s_ + 1) & 1, s_ + 1);
+        const char* s = smem + (s_ & 1) * STAGE;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 af[2], bf[2];
+                const int ca = ((2 * ks + h) ^ a_swz[t]) << 4, cb = ((2 * ks + h) ^ b_swz) << 4;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(s + a_off[t] + i * 2048 + ca);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *(const f16x8*)(s + b_off + (t * 64 + j * 32) * 64 + cb);
+                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (relu_in) af[i] = __builtin_elementwise_max(af[i], z);
+                    if (t == 0) af[i] = edge_l[i] ? z : af[i];
+                    if (t == 2) af[i] = edge_r[i] ? z : af[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = Elem<f16>::mfma(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+    // epilogue: bias (+ ReLU) -> f16, through a wave-private [64 pixels][64 channels] LDS image so that every global store
+    // is a 16-byte piece of a 128-byte output row
+    __syncthreads();
+    f16* ep = (f16*)(smem + wave * 8192);
+    const bool relu_out = (a.relu & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + l31;
+        const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bv;
+                if (relu_out) v = fmaxf(v, 0.f);
+                ep[(i * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 64 + n] = (f16)v;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ch = lane + 64 * q, row = ch >> 3, c8 = (ch & 7) * 8;
+        const int m = m0 + wave * 64 + row;
+        if (m < a.M && c8 < a.Cout) {
+            const f16x8 v = *(const f16x8*)(ep + row * 64 + c8);
+            __builtin_nontemporal_store(v, (f16x8*)(a.out + (size_t)m * a.ldo + c8));
+        }
+    }
+}
+
+int launch_conv3_n64(const void* x, int B, int H, int W, int Cin, const void* w, int Cout, const void* zero_page,
+                     const VlmoEpilogue* e, hipStream_t stream) {
+    Conv3Args a{(const f16*)x, (const f16*)w, (const f16*)zero_page, e->bias, (f16*)e->out, B * H * W, H, W, Cin, Cout,
+                e->ldo, e->relu};
+    constexpr int LDS = 2 * ((256 + 16) * 64 + 3 * 64 * 64);
+    static DeviceOnce once;
+    if (once.first())
+        (void)hipFuncSetAttribute((const void*)conv3_n64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const int grid = (a.M + 255) / 256;
+    hipLaunchKernelGGL(conv3_n64_kernel, dim3(grid), dim3(256), LDS, stream, a);
+    VLMO_CHECK_LAUNCH("vlmo_conv2d_nhwc");
+    return 0;
+}
+}  // namespace
+
 // 2-D convolution, stride 1, "same" zero padding (kw-1)/2, over an NHWC activation matrix
 // x [B*H*W, Cin] with weights w [Cout, kw*kw*Cin] (tap-major, channel-minor): dall_e/utils.py:37-48.
 extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H, int W, int Cin, int kw,
@@ -1422,8 +1590,15 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     ProfScope prof(32 + epi, 2.0 * B * H * W * Cout * K, stream);
     // <= 64 output channels (the bottleneck convolutions of the dVAE's first group, 112 x 112 x 64): a 256 x 64 tile --
     // with the 128-wide tile half of every MFMA and half of the weight staging multiplied padding
-    if (dtype == VLMO_F16 && Cout <= 64 && epi == EPI_BIAS)
+    if (dtype == VLMO_F16 && Cout <= 64 && epi == EPI_BIAS) {
+        static const bool shared_dx = [] {
+            const char* v = getenv("VLMO_CONV3_DX");        // A/B: 0 = the generic per-tap kernel
+            return !(v && v[0] == '0');
+        }();
+        if (kw == 3 && shared_dx && Cout % 8 == 0 && e->ldo % 8 == 0)
+            return launch_conv3_n64(x, B, H, W, Cin, w, Cout, zero_page, e, stream);
         return launch_nt<f16, 256, 64, 4, 1, true, 64, 2, false, (1u << EPI_BIAS)>(epi, p, stream);
+    }
     if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);
 }
