@@ -237,6 +237,9 @@ template <int BK> __device__ __forceinline__ int nt_swz(int row) {
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool CONV, int BK, int NSTG, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGroups gp) {
     typedef typename Elem<T>::v8 v8;
+    // two-segment reduction (vlmo_gemm_nt_2src): instantiated for the f16 (dVAE) kernels only -- the extra branch in the
+    // staging step cost the bf16 256x128x32 kernels of the transformer (fc1, qkv) 8-10 %
+    constexpr bool SEG2 = __is_same(T, f16) && !CONV;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int ROWB = BK * 2, CPR = ROWB / 16, SRPI = 1024 / ROWB, KS = BK / 16;
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                 glds16(src, s + (i * NW + wave) * 1024);
             }
         } else {
-            if (pp->k1 && kt * BK == pp->k1) {
+            if (SEG2 && pp->k1 && kt * BK == pp->k1) {
                 // second A segment: the same rows of A2, rebased so that `+ kt * BK` keeps addressing the reduction index
                 const T* A2_ = (const T*)pp->A2;
 #pragma unroll
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
     // first K-tile of the second A segment: the first segment's partial sum takes its scale (EncoderBlock tail:
     // post_gain * res_path + id_path as ONE reduction over [conv_3 output | block input])
     auto seg_boundary = [&](int kt) {
-        if constexpr (!CONV) {
+        if constexpr (SEG2) {
             if (pp->k1 && kt * BK == pp->k1 && pp->seg_scale != 1.f) {
                 const float sc = pp->seg_scale;
 #pragma unroll
@@ -1184,6 +1187,7 @@ extern "C" int vlmo_gemm_nt_2src(int epi, int dtype, int tile, const void* A, in
                                  const void* A2, int lda2, const void* B, int ldb, int M, int N, int K,
                                  const VlmoEpilogue* e, hipStream_t stream) {
     VLMO_CHECK_ARG(A2 && k1 > 0 && k1 < K && k1 % 64 == 0, "vlmo_gemm_nt_2src: need 0 < k1 < K, k1 %% 64 == 0 (k1=%d, K=%d)", k1, K);
+    VLMO_CHECK_ARG(dtype == VLMO_F16, "vlmo_gemm_nt_2src: instantiated for f16 (the dVAE encoder) only");
     VLMO_CHECK_ARG(lda % 8 == 0 && lda >= k1 && lda2 % 8 == 0 && lda2 >= K - k1, "vlmo_gemm_nt_2src: bad lda/lda2 %d/%d", lda, lda2);
     if (int rc = check_nt(epi, A, K > lda ? K : lda, B, ldb, M, N, K, e)) return rc;
     GemmNTGroups gp{};

@@ -91,7 +91,7 @@ int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda, const voi
  * matrices with the same rows (own leading dimensions) against ONE weight matrix [N, K].  dall_e EncoderBlock tail
  * (dall_e/encoder.py:45-46): id_path(x) + post_gain * res_path(x) with a convolutional id_path = one GEMM over
  * [conv_3 output | x] against [conv_4.w | id_path.w]; output convolution with the fp32 weight split [w_hi | w_lo]:
- * A2 = A (the activations are read twice instead of being concatenated in HBM).  k1 % 64 == 0. */
+ * A2 = A (the activations are read twice instead of being concatenated in HBM).  k1 % 64 == 0; dtype VLMO_F16 only. */
 int vlmo_gemm_nt_2src(int epi, int dtype, int tile, const void* A, int lda, int k1, float seg_scale, const void* A2,
                       int lda2, const void* B, int ldb, int M, int N, int K, const VlmoEpilogue* e,
                       hipStream_t stream);

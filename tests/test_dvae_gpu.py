@@ -160,7 +160,7 @@ def test_encoder_input_checks():
 
 @pytest.mark.parametrize('M,N,k1,k2,dt,scale', [(300, 256, 128, 256, torch.float16, 1 / 64),      # EncoderBlock tail, small tiles
                                                 (1000, 512, 1024, 1024, torch.float16, 1.0),     # [x | x] . [w_hi | w_lo], 256x256 ping-pong
-                                                (257, 768, 64, 1536, torch.bfloat16, 0.5)])
+                                                (257, 768, 64, 1536, torch.float16, 0.5)])
 def test_gemm_nt_two_segments(M, N, k1, k2, dt, scale):
     """vlmo_gemm_nt_2src: out = seg_scale * A W1^T + A2 W2^T + bias with W = [W1 | W2] one matrix; both sources with
     their own leading dimension (A is a column slice of a wider buffer)."""
@@ -182,3 +182,5 @@ def test_gemm_nt_two_segments(M, N, k1, k2, dt, scale):
         assert (out.float() - ref2).abs().max().item() <= tol * (1 + ref2.abs().max().item())
     with pytest.raises(RuntimeError, match='k1'):
         hip.gemm_nt(hip.EPI_BIAS, A, W, M, N, k1 + k2, out, bias=b, A2=A2, k1=k1 + 8)
+    with pytest.raises(RuntimeError, match='f16'):
+        hip.gemm_nt(hip.EPI_BIAS, A.bfloat16(), W.bfloat16(), M, N, k1 + k2, out.bfloat16(), bias=b, A2=A2.bfloat16(), k1=k1)
