@@ -419,6 +419,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             }
         }
     };
+    // EncoderBlock tail (EPI_DUAL, K = n_hid = 64 .. 512): the kernel is a read of the identity map and a write of the
+    // output around a one-tile product; with the identity rows fetched in the epilogue passes (8 bytes per lane, 4 KB
+    // per wave in flight) a CU pulled 11 GB/s.  All of a wave's identity segments are requested BEFORE the K loop
+    // instead: they fly under the operand staging.
+    constexpr bool PRE = (EPI == EPI_DUAL) && !PP && !CONV;
+    constexpr int PRE_LPR = TN * 8, PRE_RPI = 64 / PRE_LPR, PRE_NIT = 32 / PRE_RPI;
+    typename Elem<T>::v4 pre[PRE ? TM : 1][PRE ? PRE_NIT : 1];
+    if constexpr (PRE) {
+        if (p.e.resid) {
+            const int gn_ = n0 + wn * (BN / WN) + (lane % PRE_LPR) * 4;
+            const int gnc_ = gn_ < p.N ? gn_ : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int gmbc_ = min(m0 + wm * (BM / WM) + i * 32, p.M - 1);
+#pragma unroll
+                for (int it = 0; it < PRE_NIT; ++it) {
+                    const int rowc_ = min(it * PRE_RPI + lane / PRE_LPR, p.M - 1 - gmbc_);
+                    pre[i][it] = NT_LD((const typename Elem<T>::v4*)((const T*)p.e.resid + (size_t)(gmbc_ + rowc_) * p.e.ldo + gnc_));
+                }
+            }
+        }
+    }
     stage(0, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -528,7 +550,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
-            ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
+            if constexpr (PRE) {
+                const typename Elem<T>::v4 q = pre[i][it];
+                ext[it] = p.e.resid ? f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
+            }
             rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
         }
 #pragma unroll
@@ -1428,41 +1455,49 @@ struct Conv3Args {
     int M, H, W, Cin, Cout, ldo, relu;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3_n64_kernel(const Conv3Args a) {
-    constexpr int BM = 256, HALO = 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 64, B_BYTES = 3 * 64 * 64;
-    constexpr int STAGE = A_BYTES + B_BYTES, NAI = AROWS / 16, NBI = 3 * 64 / 16;      // 17 + 12 one-KiB pieces per step
+// WM x WN waves of 64 pixels x 64 channels: <4, 1> = 256 x 64 tile (<= 64 output channels), <2, 2> = 128 x 128 tile
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3_dx_kernel(const Conv3Args a) {
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = WM * 64, BN = WN * 64, HALO = 8, AROWS = BM + 2 * HALO;
+    constexpr int A_BYTES = AROWS * 64, B_BYTES = 3 * BN * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int NAI = AROWS / 16, NBI = 3 * BN / 16;      // one-KiB staging pieces per step (17 + 12 or 9 + 24)
+    constexpr int NAS = (NAI + 3) / 4, NBS = NBI / 4;       // ... per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
     const int HW = a.H * a.W, Cin = a.Cin, K = 9 * Cin;
     const int cpt = Cin >> 5, nsteps = 3 * cpt;
 
     // staging sources: piece ii = i * 4 + wave covers LDS rows ii * 16 .. + 15, lane -> (row, 16-byte chunk of 4)
-    const f16* a_src[5];
-    int a_y[5];
+    const f16* a_src[NAS];
+    int a_y[NAS];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NAS; ++i) {
         const int rr = (i * 4 + wave) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ nt_swz<32>(rr);
         const int pix = min(max(m0 - HALO + rr, 0), a.M - 1);
         a_src[i] = a.x + (size_t)pix * Cin + c * 8;
         a_y[i] = (pix % HW) / a.W;
     }
-    const f16* b_src[3];
+    const f16* b_src[NBS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int rr = (i * 4 + wave) * 16 + (lane >> 2);      // 0..191 = tap dx * 64 + output channel
+    for (int i = 0; i < NBS; ++i) {
+        const int rr = (i * 4 + wave) * 16 + (lane >> 2);      // tap dx * BN + output channel of the tile
         const int c = (lane & 3) ^ nt_swz<32>(rr);
-        const int n = min(rr & 63, a.Cout - 1);
-        b_src[i] = a.w + (size_t)n * K + (rr >> 6) * Cin + c * 8;
+        const int n = min(n0 + rr % BN, a.Cout - 1);
+        b_src[i] = a.w + (size_t)n * K + (rr / BN) * Cin + c * 8;
     }
     auto stage = [&](int buf, int s_) {
         char* s = smem + buf * STAGE;
         const int dyi = s_ / cpt, hc = s_ - dyi * cpt, dy = dyi - 1;
         const int delta = dy * a.W * Cin + hc * 32;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NAS; ++i) {
             if (i * 4 + wave < NAI) {
                 const bool in = (unsigned)(a_y[i] + dy) < (unsigned)a.H;
                 glds16(in ? a_src[i] + delta : a.zero, s + (i * 4 + wave) * 1024);
@@ -1470,25 +1505,24 @@ __global__ __launch_bounds__(256, 2) void conv3_n64_kernel(const Conv3Args a) {
         }
         const int wofs = dyi * 3 * Cin + hc * 32;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) glds16(b_src[i] + wofs, s + A_BYTES + (i * 4 + wave) * 1024);
+        for (int i = 0; i < NBS; ++i) glds16(b_src[i] + wofs, s + A_BYTES + (i * 4 + wave) * 1024);
     };
-    static_assert(NBI == 12, "three weight pieces per wave");
 
     const int l31 = lane & 31, h = lane >> 5;
-    // A fragment of tap dx, row block i: LDS row HALO + wave * 64 + i * 32 + l31 + dx (the swizzle key of a row does not
-    // change with + 32); B fragment: row dxi * 64 + j * 32 + l31
+    // A fragment of tap dx, row block i: LDS row HALO + wm * 64 + i * 32 + l31 + dx (the swizzle key of a row does not
+    // change with + 32); B fragment: row dxi * BN + wn * 64 + j * 32 + l31
     int a_off[3], a_swz[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int row = HALO + wave * 64 + l31 + (t - 1);
+        const int row = HALO + wm * 64 + l31 + (t - 1);
         a_off[t] = row * 64;
         a_swz[t] = nt_swz<32>(row);
     }
-    const int b_off = A_BYTES + l31 * 64, b_swz = nt_swz<32>(l31);
+    const int b_off = A_BYTES + (wn * 64 + l31) * 64, b_swz = nt_swz<32>(l31);
     bool edge_l[2], edge_r[2];      // the lane's pixel has no left / right neighbour in its image row
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int xx = (m0 + wave * 64 + i * 32 + l31) % a.W;
+        const int xx = (m0 + wm * 64 + i * 32 + l31) % a.W;
         edge_l[i] = xx == 0;
         edge_r[i] = xx == a.W - 1;
     }
@@ -1516,7 +1550,7 @@ __global__ __launch_bounds__(256, 2) void conv3_n64_kernel(const Conv3Args a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(s + a_off[t] + i * 2048 + ca);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *(const f16x8*)(s + b_off + (t * 64 + j * 32) * 64 + cb);
+                for (int j = 0; j < 2; ++j) bf[j] = *(const f16x8*)(s + b_off + (t * BN + j * 32) * 64 + cb);
                 const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -1532,13 +1566,14 @@ __global__ __launch_bounds__(256, 2) void conv3_n64_kernel(const Conv3Args a) {
         }
     }
     // epilogue: bias (+ ReLU) -> f16, through a wave-private [64 pixels][64 channels] LDS image so that every global store
-    // is a 16-byte piece of a 128-byte output row
+    // is a 16-byte piece of a 128-byte run of an output row
     __syncthreads();
     f16* ep = (f16*)(smem + wave * 8192);
     const bool relu_out = (a.relu & 1) != 0;
+    const int nw0 = n0 + wn * 64;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = j * 32 + l31;
+        const int n = nw0 + j * 32 + l31;
         const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1546,31 +1581,33 @@ __global__ __launch_bounds__(256, 2) void conv3_n64_kernel(const Conv3Args a) {
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] + bv;
                 if (relu_out) v = fmaxf(v, 0.f);
-                ep[(i * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 64 + n] = (f16)v;
+                ep[(i * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 64 + j * 32 + l31] = (f16)v;
             }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int ch = lane + 64 * q, row = ch >> 3, c8 = (ch & 7) * 8;
-        const int m = m0 + wave * 64 + row;
-        if (m < a.M && c8 < a.Cout) {
+        const int m = m0 + wm * 64 + row;
+        if (m < a.M && nw0 + c8 < a.Cout) {
             const f16x8 v = *(const f16x8*)(ep + row * 64 + c8);
-            __builtin_nontemporal_store(v, (f16x8*)(a.out + (size_t)m * a.ldo + c8));
+            __builtin_nontemporal_store(v, (f16x8*)(a.out + (size_t)m * a.ldo + nw0 + c8));
         }
     }
 }
 
-int launch_conv3_n64(const void* x, int B, int H, int W, int Cin, const void* w, int Cout, const void* zero_page,
-                     const VlmoEpilogue* e, hipStream_t stream) {
+template <int WM, int WN>
+int launch_conv3_dx(const void* x, int B, int H, int W, int Cin, const void* w, int Cout, const void* zero_page,
+                    const VlmoEpilogue* e, hipStream_t stream) {
     Conv3Args a{(const f16*)x, (const f16*)w, (const f16*)zero_page, e->bias, (f16*)e->out, B * H * W, H, W, Cin, Cout,
                 e->ldo, e->relu};
-    constexpr int LDS = 2 * ((256 + 16) * 64 + 3 * 64 * 64);
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int LDS = 2 * ((BM + 16) * 64 + 3 * BN * 64);
     static DeviceOnce once;
     if (once.first())
-        (void)hipFuncSetAttribute((const void*)conv3_n64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    const int grid = (a.M + 255) / 256;
-    hipLaunchKernelGGL(conv3_n64_kernel, dim3(grid), dim3(256), LDS, stream, a);
+        (void)hipFuncSetAttribute((const void*)conv3_dx_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const int grid = ((a.M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv3_dx_kernel<WM, WN>), dim3(grid), dim3(256), LDS, stream, a);
     VLMO_CHECK_LAUNCH("vlmo_conv2d_nhwc");
     return 0;
 }
@@ -1592,17 +1629,18 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
     p.ngroups = 1;
     p.g[0] = GemmNT{x, w, B * H * W, Cout, K, Cin, K, *e, H, W, Cin, kw, zero_page, 8, nullptr, 0, 0, 1.f};
     ProfScope prof(32 + epi, 2.0 * B * H * W * Cout * K, stream);
-    // <= 64 output channels (the bottleneck convolutions of the dVAE's first group, 112 x 112 x 64): a 256 x 64 tile --
-    // with the 128-wide tile half of every MFMA and half of the weight staging multiplied padding
-    if (dtype == VLMO_F16 && Cout <= 64 && epi == EPI_BIAS) {
-        static const bool shared_dx = [] {
-            const char* v = getenv("VLMO_CONV3_DX");        // A/B: 0 = the generic per-tap kernel
-            return !(v && v[0] == '0');
-        }();
-        if (kw == 3 && shared_dx && Cout % 8 == 0 && e->ldo % 8 == 0)
-            return launch_conv3_n64(x, B, H, W, Cin, w, Cout, zero_page, e, stream);
-        return launch_nt<f16, 256, 64, 4, 1, true, 64, 2, false, (1u << EPI_BIAS)>(epi, p, stream);
+    static const bool shared_dx = [] {
+        const char* v = getenv("VLMO_CONV3_DX");        // A/B: 0 = the generic per-tap kernels
+        return !(v && v[0] == '0');
+    }();
+    if (dtype == VLMO_F16 && epi == EPI_BIAS && kw == 3 && shared_dx && Cin % 32 == 0 && Cout % 8 == 0 && e->ldo % 8 == 0) {
+        if (Cout <= 64) return launch_conv3_dx<4, 1>(x, B, H, W, Cin, w, Cout, zero_page, e, stream);
+        return launch_conv3_dx<2, 2>(x, B, H, W, Cin, w, Cout, zero_page, e, stream);
     }
+    // <= 64 output channels: a 256 x 64 tile -- with the 128-wide tile half of every MFMA and half of the weight staging
+    // multiplied padding
+    if (dtype == VLMO_F16 && Cout <= 64 && epi == EPI_BIAS)
+        return launch_nt<f16, 256, 64, 4, 1, true, 64, 2, false, (1u << EPI_BIAS)>(epi, p, stream);
     if (dtype == VLMO_F16) return launch_nt<f16, 128, 128, 2, 2, true>(epi, p, stream);
     return launch_nt<bf16, 128, 128, 2, 2, true>(epi, p, stream);
 }
