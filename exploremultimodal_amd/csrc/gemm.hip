@@ -468,6 +468,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[q][j] = *(const v8*)(s_ + b_row_off + j * 32 * ROWB + coff);
             }
+            if constexpr (CONV && sizeof(T) == 2 && __is_same(T, f16)) {
+                if (pp->e.relu & 2) {       // ReLU on the convolution's input (see compute())
+                    const v8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[q][i] = __builtin_elementwise_max(af[q][i], z);
+                }
+            }
         };
         auto mfma_half = [&]() {
             __builtin_amdgcn_s_setprio(1);
@@ -1633,6 +1642,17 @@ extern "C" int vlmo_conv2d_nhwc(int epi, int dtype, const void* x, int B, int H,
         const char* v = getenv("VLMO_CONV3_DX");        // A/B: 0 = the generic per-tap kernels
         return !(v && v[0] == '0');
     }();
+    // wide bottlenecks whose 256 x 256 tiles fill most of one dispatch round (group 3 of the dVAE at 64 images: 196 tiles):
+    // the ping-pong kernel with per-tap staging -- half the staged bytes per flop of the 128 x 128 tile
+    static const bool pp_conv = [] {
+        const char* v = getenv("VLMO_CONV_PP");
+        return !(v && v[0] == '0');
+    }();
+    if (dtype == VLMO_F16 && epi == EPI_BIAS && pp_conv && Cout % 256 == 0) {
+        const long t256 = (long)((B * H * W + 255) / 256) * (Cout / 256);
+        if (t256 >= 160 && (t256 <= 256 || t256 >= 640))
+            return launch_nt<f16, 256, 256, 2, 4, true, 64, 2, true, (1u << EPI_BIAS)>(epi, p, stream);
+    }
     if (dtype == VLMO_F16 && epi == EPI_BIAS && kw == 3 && shared_dx && Cin % 32 == 0 && Cout % 8 == 0 && e->ldo % 8 == 0) {
         if (Cout <= 64) return launch_conv3_dx<4, 1>(x, B, H, W, Cin, w, Cout, zero_page, e, stream);
         return launch_conv3_dx<2, 2>(x, B, H, W, Cin, w, Cout, zero_page, e, stream);
