@@ -27,7 +27,9 @@ def _nhwc(x):      # [B,C,H,W] -> [B*H*W, C]
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,kw', [(2, 12, 12, 64, 64, 3), (1, 16, 20, 128, 256, 3),
                                                (2, 7, 9, 64, 128, 1), (3, 14, 14, 256, 64, 3),
-                                               (11, 64, 60, 64, 256, 3)])      # 165 tiles of 256 x 256: the ping-pong kernel
+                                               (11, 64, 60, 64, 256, 3),       # 165 tiles of 256 x 256: the ping-pong kernel
+                                               (2, 9, 11, 64, 32, 3), (1, 10, 12, 64, 192, 3),     # ragged channel tiles of the shared-dx kernels
+                                               (1, 5, 7, 128, 36, 3)])         # 36 channels: not a multiple of 8 -> generic kernel
 def test_conv2d_nhwc_vs_torch(B, H, W, Cin, Cout, kw):
     g = torch.Generator().manual_seed(Cin + Cout + kw)
     x = torch.randn(B, Cin, H, W, generator=g).half().to(DEV)
