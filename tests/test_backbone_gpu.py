@@ -329,3 +329,38 @@ def test_full_batch_against_oracle(preset, B, out_tol, mean_tol, grad_tol):
         worst = max(worst, (rel, k))
         assert rel <= grad_tol, (k, rel)
     print(f'{preset} B={B}: ' + 'max err %.4f mean %.5f worst grad %.4f (%s)' % (err.max().item(), err.mean().item(), *worst))
+
+
+def test_second_backward_accumulates_in_place():
+    """A second backward pass over parameters that already hold the engine's gradient views (another objective of the
+    step, or a gradient-accumulation micro-step; multimodal.py:260,316-323) adds into them inside the weight-gradient
+    kernels: same storage afterwards, values = sum of the two passes."""
+    model, mc = build('mini')
+    model.eval()
+    batch = synth.synth_batch(mc, 3, seed=5)
+    kw = modes(mc, batch, 3)
+    blk = [p for n, p in model.named_parameters() if 'blocks.' in n]
+
+    def run(mode, scale):
+        x, _ = model.forward_features(**kw[mode])
+        (x.float().square().mean() * scale).backward()
+
+    run('vl', 1.0)
+    torch.cuda.synchronize()
+    first = {id(p): (p.grad.data_ptr(), p.grad.clone()) for p in blk if p.grad is not None}
+    assert first
+    run('vl', 2.0)          # same pass again, twice the loss: every gradient must become 3x the first one
+    torch.cuda.synchronize()
+    for p in blk:
+        if p.grad is None:
+            continue
+        ptr, g1 = first[id(p)]
+        assert p.grad.data_ptr() == ptr                         # accumulated in place, not replaced by autograd's sum
+        ref = 3.0 * g1
+        assert torch.allclose(p.grad, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item() + 1e-12)
+    # an image-only pass touches the image experts and the shared parameters only: text-expert gradients stay as they are
+    before = {id(p): p.grad.clone() for p in blk if p.grad is not None}
+    run('v', 1.0)
+    torch.cuda.synchronize()
+    changed = sum(int(not torch.equal(p.grad, before[id(p)])) for p in blk if id(p) in before)
+    assert 0 < changed < len(before)      # (the image experts of the fusion layers get their first gradient here)
