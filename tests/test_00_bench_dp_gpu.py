@@ -1,7 +1,10 @@
 """`python bench.py --gpus 2` from a plain shell on the GPU box: the self-launcher starts two ranks (both on the box's one
 GPU, gradient exchange over gloo: --rehearse-gloo), each runs the data-parallel step -- GradReducer with the engine's
 gradient sinks, per-block ready events, pack / collective / unpack on the communication stream -- and rank 0 prints the
-ONE JSON line of the bench contract with n_gpus = 2.  What the driver's N > 1 runs do, minus RCCL's links."""
+ONE JSON line of the bench contract with n_gpus = 2.  What the driver's N > 1 runs do, minus RCCL's links.
+
+The file name sorts first on purpose: the children must be started from a process that has NOT initialised the GPU (this
+pool refuses an exec from one that has), i.e. before any other GPU test of the session ran in this interpreter."""
 import json
 import os
 import subprocess
@@ -14,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_two_rank_rehearsal_prints_one_json_line():
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip('the test runner has already initialised the GPU: starting other programs from it is not allowed here')
     env = dict(os.environ)
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
