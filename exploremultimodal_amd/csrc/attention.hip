@@ -2,9 +2,13 @@
 // Reference: Attention.forward, vlmo.py:79-95:
 //   attn = softmax((q k^T) * dh^-0.5 + keymask(-inf)) ; dropout ; ctx = attn v
 // VLMo sequences are short (64 / 197 / 261 tokens), so a whole head's K and V
-// sit in LDS (<= 36 KB each) and a wavefront keeps a complete 32-query x N-key
-// score tile in registers: exact softmax, no online rescaling, no N x N tensor
-// in HBM (the reference materialises [B,h,N,N] several times).
+// sit in LDS (<= 36 KB each) and the scores of a 32-query tile never leave
+// registers: no N x N tensor in HBM (the reference materialises [B,h,N,N]
+// several times).  Forward: attn_fwd1_kernel (one wave per query tile, key
+// tiles one at a time with a lazily rescaled running maximum; sequences of up
+// to 288 tokens) and attn_fwd_kernel (128-key chunks with an exact running
+// maximum; longer sequences).  Backward: attn_bwd1_kernel (single pass, up to
+// 256 tokens) and attn_bwd_kernel (two phases, up to 288).
 //
 // Orientation: scores are computed TRANSPOSED, S^T[key][query] = K . Q^T, so a
 // lane owns one query column (softmax reductions are in-register + one
