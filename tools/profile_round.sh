@@ -18,6 +18,14 @@ VLMO_OVERLAP_WGRAD=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/
 echo "serial stats done" >> $OUT/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/dvae -o s --output-format csv -- python3 tools/dvae_bench.py > $OUT/dvae.log 2>&1
 echo "dvae stats done" >> $OUT/progress.txt
+# the data-parallel step at world 1 through either communicator, and the four-objective step (summaries only)
+for m in torch native; do
+  VLMO_DP_COMM=$m timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/red_$m -o s --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline --force-reducer > $OUT/red_$m.log 2>&1
+  python3 tools/summarize_profile.py $OUT/red_$m/s_kernel_stats.csv $TOTAL > $OUT/${TAG}_reducer_${m}_summary.json
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/full -o s --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --batch 32 --objective full --merge-passes > $OUT/full.log 2>&1
+python3 tools/summarize_profile.py $OUT/full/s_kernel_stats.csv 11 > $OUT/${TAG}_full_objective_summary.json
+echo "reducer / full-objective stats done" >> $OUT/progress.txt
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o c --output-format csv -- python3 bench.py --steps $K --warmup $W --no-cpu-baseline "$@" > $OUT/$C.log 2>&1
   echo "$C done" >> $OUT/progress.txt
