@@ -47,6 +47,28 @@ class ShadowCache:
             self._c[key] = ent
         return ent[1], ent[2]
 
+    def refresh(self, params):
+        """Bring the shadows of `params` (2-D weights, W and W^T) up to date in ONE launch: after an optimizer step every
+        weight is stale, and one cast launch per weight was 0.65 ms of an 18 ms training step.  Buffers of an unchanged
+        shape are overwritten in place (the cast is ordered behind the step's kernels on the caller's stream)."""
+        jobs = []
+        for p in params:
+            key = id(p)
+            ent = self._c.get(key)
+            ver = (p._version, p.data_ptr())
+            if ent is not None and ent[0] == ver and ent[2] is not None:
+                continue
+            w2 = p.detach().reshape(p.shape[0], -1)
+            if ent is not None and ent[1].shape == w2.shape and ent[2] is not None:
+                w, wt = ent[1], ent[2]
+            else:
+                w = torch.empty(w2.shape, dtype=torch.bfloat16, device=p.device)
+                wt = torch.empty((w2.shape[1], w2.shape[0]), dtype=torch.bfloat16, device=p.device)
+            jobs.append((w2, w, wt))
+            self._c[key] = (ver, w, wt)
+        if jobs:
+            hip.cast_weight_multi(jobs)
+
     def qkv_bias(self, q_bias, v_bias):
         """cat(q_bias, 0, v_bias) (vlmo.py:72-75), cached until either parameter changes."""
         key = ('qkvb', id(q_bias))
@@ -558,6 +580,14 @@ class StackFn(torch.autograd.Function):
         X2 = torch.empty((nb if need_bwd else min(nb, 2), M, d), dtype=torch.float32, device=dev)
         descs = (hip.BlockDesc * nb)()
         keep = [SB, SF, X2, pl]
+        if m0.shadows is not None:          # every stale weight shadow of the pass in one launch (ShadowCache.refresh)
+            stale, po = [], 0
+            for mt in metas:
+                ne = len(mt.expert_ranges)
+                bp = params[po:po + 11 + 4 * ne]
+                po += 11 + 4 * ne
+                stale += [bp[4], bp[7]] + [bp[11 + 4 * e] for e in range(ne)] + [bp[13 + 4 * e] for e in range(ne)]
+            m0.shadows.refresh(stale)
         pofs, sf_off = 0, 0
         xin = x.data_ptr()
         spans = []

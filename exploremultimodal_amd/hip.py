@@ -89,6 +89,7 @@ _SIGS = {
     'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp, _i64, _vp],
     'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp],
     'vlmo_cast_weight': [_i32, _vp, _i32, _i32, _vp, _vp, _vp],
+    'vlmo_cast_weight_multi': [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     'vlmo_patchify': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'vlmo_embed_img_finish': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _u32, _f32,
                               _u64, _vp],
@@ -328,6 +329,20 @@ def cast_weight(src, dst, dstT):
     ref = dst if dst is not None else dstT
     rc = lib().vlmo_cast_weight(_dt(ref), _p(src), rows, cols, _p(dst), _p(dstT), _stream())
     _check(rc, 'vlmo_cast_weight')
+
+
+def cast_weight_multi(jobs):
+    """jobs: [(src fp32 [rows, cols], dst or None, dstT or None)] -> one launch (per 72 jobs)."""
+    n = len(jobs)
+    if n == 0:
+        return
+    ref = jobs[0][1] if jobs[0][1] is not None else jobs[0][2]
+    src = (ctypes.c_void_p * n)(*[_p(a) for a, _, _ in jobs])
+    dst = (ctypes.c_void_p * n)(*[_p(b) for _, b, _ in jobs])
+    dstT = (ctypes.c_void_p * n)(*[_p(c) for _, _, c in jobs])
+    rows = (ctypes.c_int32 * n)(*[a.shape[0] for a, _, _ in jobs])
+    cols = (ctypes.c_int32 * n)(*[a.shape[1] for a, _, _ in jobs])
+    _check(lib().vlmo_cast_weight_multi(_dt(ref), n, src, rows, cols, dst, dstT, _stream()), 'vlmo_cast_weight_multi')
 
 
 def patchify(img, out, patch):

@@ -195,6 +195,10 @@ int vlmo_colwork_multi(int dtype, const VlmoColJob* jobs, int n, hipStream_t str
 /* fp32 -> bf16/f16 weight shadow copies: dst = cast(src), dstT = cast(src)^T (either may be NULL). */
 int vlmo_cast_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT,
                      hipStream_t stream);
+/* n weights in one launch (every weight of the model is stale after an optimizer step): job q casts src[q] [rows[q], cols[q]]
+ * fp32 into dst[q] (same layout, may be NULL) and dstT[q] (transposed, may be NULL). */
+int vlmo_cast_weight_multi(int dtype, int n, const float* const* src, const int32_t* rows, const int32_t* cols,
+                           void* const* dst, void* const* dstT, hipStream_t stream);
 
 /* Image embedding (vlmo.py:298-319, timm PatchEmbed):
  *  patchify: image f32 [B,C,H,W] -> bf16 [B*gh*gw, C*p*p] rows ordered (b, py, px), cols (c, ky, kx)

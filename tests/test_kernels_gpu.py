@@ -598,3 +598,21 @@ def test_gemm_tn_multi_more_tiles_than_one_placement_table():
     torch.cuda.synchronize()
     for p, r in zip(probs, refs):
         assert torch.equal(p[2].cpu(), r)
+
+
+def test_cast_weight_multi_matches_single():
+    """vlmo_cast_weight_multi: every job's W and W^T copies equal the one-weight kernel's (ragged shapes, > 72 jobs)."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(768, 768), (2304, 768), (3072, 768), (768, 3072), (100, 36), (33, 65), (8, 4)] * 12      # 84 jobs
+    jobs, want = [], []
+    for r, c in shapes:
+        src = torch.randn(r, c, generator=g).to(DEV)
+        w, wt = torch.empty(r, c, dtype=torch.bfloat16, device=DEV), torch.empty(c, r, dtype=torch.bfloat16, device=DEV)
+        jobs.append((src, w, wt))
+        want.append((src.bfloat16(), src.t().contiguous().bfloat16()))
+    jobs[3] = (jobs[3][0], jobs[3][1], None)          # no transposed copy for this one
+    hip.cast_weight_multi(jobs)
+    for q, ((_, w, wt), (rw, rwt)) in enumerate(zip(jobs, want)):
+        assert torch.equal(w, rw), q
+        if wt is not None:
+            assert torch.equal(wt, rwt), q
