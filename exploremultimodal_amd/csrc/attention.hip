@@ -40,6 +40,8 @@ struct AttnArgs {
     uint32_t drop_thresh, drop_cmp;     // drop_cmp = thresh << 16: keep <=> att_mix(...) >= drop_cmp
     float inv_keep;
     uint64_t seed;
+    int bh0;             // dropout-mask index of the launch's first (sequence, head): a backward launch over a SUFFIX of the
+                         // forward launch's sequences regenerates the forward's mask (vlmo.py:93 has one mask per call)
 };
 
 #define LOG2E 1.4426950408889634f
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a, cons
     __syncthreads();
 
     const int l31 = lane & 31, h = lane >> 5;
-    const uint32_t akey = att_key(a.seed, bh);
+    const uint32_t akey = att_key(a.seed, bh + a.bh0);
     for (int qt = wave; qt < nq; qt += 4) {
         const int qi = qt * 32 + l31;
         const int qrow = rowidx[qi];
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(576) void attn_fwd1_kernel(const AttnArgs a, const 
         return acc;
     };
 
-    const uint32_t akey = att_key(a.seed, bh);
+    const uint32_t akey = att_key(a.seed, bh + a.bh0);
     const uint32_t rq = ((uint32_t)qi * 512u + 4u * h) * ATT_G + akey;
     const float c2 = a.scale_log2e;
     const float thr = 8.f / c2;             // lazy-rescale threshold in raw score units
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     __syncthreads();
 
     const int l31 = lane & 31, h = lane >> 5;
-    const uint32_t akey = att_key(a.seed, bh);
+    const uint32_t akey = att_key(a.seed, bh + a.bh0);
     // the constant factors of dS = P * (keep * dP * inv_keep - delta) * scale and Pd = keep * P * inv_keep are
     // applied ONCE to the 32 accumulator values a lane owns, not to every score element
     const float out_scale = a.scale * a.inv_keep;
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const uint32_t akey = att_key(a.seed, bh);
+    const uint32_t akey = att_key(a.seed, bh + a.bh0);
     const float out_scale = a.scale * a.inv_keep;
     const float c_l2 = a.scale_log2e;
     const float kb = kbias[min(ki, NPAD - 1)];
@@ -1069,7 +1071,7 @@ int check_common(const char* fn, const void* qkv, const int32_t* seg, int num_se
 
 extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, const int32_t* keymask, void* ctx,
                              float* lse, int lse_stride, int heads, int d, int max_len, float scale,
-                             uint32_t drop_thresh, float inv_keep, uint64_t seed, hipStream_t stream) {
+                             uint32_t drop_thresh, float inv_keep, uint64_t seed, int mask_seq0, hipStream_t stream) {
     if (int rc = check_common("vlmo_attn_fwd", qkv, seg, num_seq, heads, d, max_len, 576)) return rc;
     VLMO_CHECK_ARG(ctx, "vlmo_attn_fwd: null ctx");
     VLMO_CHECK_ARG(!lse || lse_stride >= max_len, "vlmo_attn_fwd: lse_stride too small");
@@ -1088,6 +1090,7 @@ extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, c
     a.drop_cmp = drop_thresh >= 65536u ? 0xFFFFFFFFu : drop_thresh << 16;
     a.inv_keep = drop_thresh ? inv_keep : 1.f;
     a.seed = seed;
+    a.bh0 = mask_seq0 * heads;
     const int nt = (max_len + 31) / 32, nb = num_seq * heads;
     static const bool chunked = [] {
         const char* e = getenv("VLMO_ATTN_FWD");
@@ -1102,7 +1105,7 @@ extern "C" int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, c
 extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, int lse_stride,
                              const int32_t* seg, int num_seq, const int32_t* keymask, void* dqkv, float* qv_colsum,
                              int heads, int d, int max_len, float scale, uint32_t drop_thresh, float inv_keep,
-                             uint64_t seed, hipStream_t stream) {
+                             uint64_t seed, int mask_seq0, hipStream_t stream) {
     if (int rc = check_common("vlmo_attn_bwd", qkv, seg, num_seq, heads, d, max_len, 288)) return rc;
     VLMO_CHECK_ARG(ctx && dctx && lse && dqkv, "vlmo_attn_bwd: null pointer");
     VLMO_CHECK_ARG(lse_stride >= max_len, "vlmo_attn_bwd: lse_stride too small");
@@ -1124,6 +1127,7 @@ extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx,
     a.drop_cmp = drop_thresh >= 65536u ? 0xFFFFFFFFu : drop_thresh << 16;
     a.inv_keep = drop_thresh ? inv_keep : 1.f;
     a.seed = seed;
+    a.bh0 = mask_seq0 * heads;
     const int nt = (max_len + 31) / 32, nb = num_seq * heads;
     static const bool two_phase = getenv("VLMO_ATTN_BWD") && !strcmp(getenv("VLMO_ATTN_BWD"), "two_phase");   // measurement aid
     if (two_phase || nt > 8)

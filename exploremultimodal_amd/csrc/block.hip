@@ -69,7 +69,7 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)(d / b->heads));
     for (int a = 0; a < b->n_attn; ++a)
         TRY(vlmo_attn_fwd(b->qkv, b->seg[a], b->nseq[a], b->keymask, b->ctx, b->lse[a], b->lse_stride[a], b->heads, d,
-                          b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep, b->seed + 11 + a, st));
+                          b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep, b->seed + 11 + b->attn_seed_idx[a], b->attn_seq0[a], st));
     {
         VlmoEpilogue e = epi();
         e.out = b->x1;
@@ -222,7 +222,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
     for (int a = 0; a < b->n_attn; ++a)
         TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
                           b->dqkv, nullptr, b->heads, d, b->maxlen[a], scale, b->attn_drop_thresh, b->attn_inv_keep,
-                          b->seed + 11 + a, st));
+                          b->seed + 11 + b->attn_seed_idx[a], b->attn_seq0[a], st));
     fork();     // one fork for the whole attention half: the proj gradient waits for it too (the side stream has slack)
     TRY(reduce_partials(pend[0], side));
     TRY(vlmo_gemm_tn(VLMO_BF16, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d, 1.f, 0, b->ws_tn, b->ws_tn_bytes, side));
@@ -390,7 +390,7 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D, const
     for (int a = 0, s0 = 0; a < b->n_attn; s0 += b->nseq[a], ++a)
         TRY(vlmo_attn_bwd(b->qkv, b->ctx, b->dctx, b->lse[a], b->lse_stride[a], b->seg[a], b->nseq[a], b->keymask,
                           b->dqkv, qvsum ? qvsum + (size_t)s0 * 2 * d : nullptr, b->heads, d, b->maxlen[a], scale,
-                          b->attn_drop_thresh, b->attn_inv_keep, b->seed + 11 + a, st));
+                          b->attn_drop_thresh, b->attn_inv_keep, b->seed + 11 + b->attn_seed_idx[a], b->attn_seq0[a], st));
     push_tn(D, b->dz1, d, b->ctx, d, b->dproj_w, d, M, d, d);
     push_tn(D, b->dqkv, 3 * d, b->y1, d, b->dqkv_w, d, M, 3 * d, d);
     if (qvsum) {

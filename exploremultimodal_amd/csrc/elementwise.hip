@@ -16,7 +16,7 @@ void vlmo_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vlmo_last_error(void) { return g_err; }
-extern "C" int vlmo_abi_version(void) { return 4; }
+extern "C" int vlmo_abi_version(void) { return 5; }
 
 namespace {
 

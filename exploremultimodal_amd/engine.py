@@ -293,6 +293,7 @@ def _fill_forward(D, meta, params, launches, lse_sizes, M, pb, pf, need_bwd, kee
         D.seg[i], D.nseq[i], D.maxlen[i] = seg.data_ptr(), nseq, ml
         D.lse_stride[i] = ((ml + 31) // 32) * 32
         D.lse[i] = off
+        D.attn_seed_idx[i], D.attn_seq0[i] = i, 0
         off += sz * 4
     D.keymask = hip._p(pl.keymask)
     D.eps = meta.eps
@@ -340,6 +341,9 @@ def _split_backward_attention(D, meta):
     D.maxlen[0], D.maxlen[1] = pl.P, pl.T
     D.lse_stride[1] = stride
     D.seg[1] = D.seg[0] + pl.B * 16                                       # 4 int32 per sequence
+    # the text launch regenerates the attention-dropout mask of ITS sequences of the shared forward launch
+    # (sequences [B, 2B) under the forward's seed), not the mask of a second forward launch
+    D.attn_seed_idx[1], D.attn_seq0[1] = D.attn_seed_idx[0], pl.B
     D.lse[1] = D.lse[0] + pl.B * meta.heads * stride * 4
 
 
@@ -445,6 +449,10 @@ class BlockFn(torch.autograd.Function):
                     [sink.acquire(g_, exp_n, dev, akey, aroom, layout=expert_layout(g_, d, hid))
                      for g_ in ctx.sink_groups[1:]]
         else:                   # ONE zero-filled flat buffer (one memset) carved into all gradients of the block
+            reg = _task_flats()
+            if reg:             # fresh gradients for these groups: later StackFn nodes of this backward must not add into
+                for g_ in [params[:11]] + [params[11 + 4 * e: 15 + 4 * e] for e in range(nexp)]:      # an earlier node's buffer
+                    reg.pop(_group_key(g_), None)
             whole = torch.zeros(shared_n + nexp * exp_n, dtype=f32, device=dev)
             flats = [whole[:shared_n]] + [whole[shared_n + i * exp_n: shared_n + (i + 1) * exp_n] for i in range(nexp)]
 
@@ -518,34 +526,76 @@ def _ready_events(dev, n):
     return evs[:n]
 
 
-INPLACE_ACCUM = _os.environ.get('VLMO_INPLACE_ACCUM', '1') != '0'
+INPLACE_ACCUM = _os.environ.get('VLMO_INPLACE_ACCUM', '1') != '0'      # kill switch for both mechanisms below
+
+# ---- in-place gradient accumulation across the backward passes of one step -------------------------------------
+# A four-objective step runs the block stack three to seven times; without a reducer every pass hands autograd a fresh
+# gradient per parameter and the engine's input buffers add them: 337 elementwise launches = 1.4 ms of a 61 ms step.
+#
+# (1) WITHIN one backward() / autograd.grad() call (always on): the first StackFn node of the graph task that reaches a
+#     parameter GROUP (a block's shared parameters, or one expert) returns views of a flat buffer and registers the
+#     buffer under the task's id; every later node of the same task accumulates INTO that buffer inside the
+#     weight-gradient kernels and returns None for the group.  The engine still holds the first node's tensors (in the
+#     AccumulateGrad input buffer, or as the captured result of autograd.grad), so what it finally accumulates or
+#     returns is the sum: .grad is never touched by us, which makes this correct under autograd.grad(...) and
+#     backward(inputs=[...]) too.  Every engine node of a task must cooperate: a BlockFn node that returns fresh
+#     gradients for a group drops the group's entry (the input buffer would add out of place and orphan our buffer).
+# (2) ACROSS backward() calls (gradient-accumulation micro-steps, zero_grad(set_to_none=False)): a pass accumulates
+#     straight into the views the parameters already hold as .grad.  That is only right in an ordinary accumulating
+#     backward(), so it is OPT-IN: `with engine.accumulate_into_grad():` around loss.backward() -- the package's
+#     NativeScalerWithGradNormCount (the reference loop's backward, utils.py:343-364) and bench.py do that.
+_TASK_FLATS = {'task': None, 'flats': {}}
+_INTO_GRAD = [False]
 
 
-def _existing_flats(bp, shared_n, exp_n, nexp):
-    """The flat gradient storage a block's parameters ALREADY hold -- the views an earlier backward pass of this step
-    returned (autograd keeps them as .grad), or the same views zeroed by zero_grad(set_to_none=False) -- so that a
-    further pass can accumulate into it in the weight-gradient kernels instead of returning fresh tensors for autograd to
-    add (one elementwise launch per parameter and pass: 337 launches = 1.4 ms of a 61 ms four-objective step).  None
-    when the layout is not ours (first pass, foreign .grad, hooks that must see every contribution)."""
-    flats = []
-    for p0, n in [(bp[0], shared_n)] + [(bp[11 + 4 * e], exp_n) for e in range(nexp)]:
-        g = p0.grad
-        base = g._base if g is not None else None
-        if base is None or g.dtype != torch.float32 or base.dim() != 1 or not base.is_contiguous():
-            return None
-        off = (g.data_ptr() - base.data_ptr()) // 4
-        if off < 0 or off + n > base.numel():
-            return None
-        flats.append(base[off:off + n])
-    return flats
+class accumulate_into_grad:
+    """Context manager: backward passes inside it may add into the gradient views parameters already hold."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _INTO_GRAD[0]
+        _INTO_GRAD[0] = self.enabled
+        return self
+
+    def __exit__(self, *a):
+        _INTO_GRAD[0] = self.prev
 
 
-def _same_views(bp, grads):
-    for p_, g_ in zip(bp, grads):
+def _task_flats():
+    """{group key: flat gradient buffer} of the running graph task (emptied when another task starts)."""
+    tid = torch._C._current_graph_task_id()
+    if _TASK_FLATS['task'] != tid:
+        _TASK_FLATS['task'], _TASK_FLATS['flats'] = tid, {}
+    return _TASK_FLATS['flats'] if tid >= 0 else None
+
+
+def _group_key(gparams):
+    # a weight matrix of the group (qkv weight / fc1 weight): gamma_1 may be a stand-in shared by all blocks (init_values=None)
+    return gparams[4].data_ptr() if len(gparams) == 11 else gparams[0].data_ptr()
+
+
+def _grad_flat(gparams, n):
+    """The flat fp32 storage the group's parameters ALREADY hold as .grad in this engine's layout (views an earlier
+    backward returned, possibly zeroed by zero_grad(set_to_none=False)), or None."""
+    g = gparams[0].grad
+    base = g._base if g is not None else None
+    if base is None or g.dtype != torch.float32 or base.dim() != 1 or not base.is_contiguous():
+        return None
+    off = (g.data_ptr() - base.data_ptr()) // 4
+    if off < 0 or off + n > base.numel():
+        return None
+    return base[off:off + n]
+
+
+def _same_views(layout, flat):
+    """Every parameter of the group holds as .grad exactly the view the layout carves out of `flat`, and nobody hooks it."""
+    for p_, off in layout:
         if not p_.requires_grad:
             continue
         pg = p_.grad
-        if pg is None or pg.data_ptr() != g_.data_ptr() or pg.shape != g_.shape or not pg.is_contiguous():
+        if pg is None or pg.data_ptr() != flat.data_ptr() + 4 * off or not pg.is_contiguous() or pg.dtype != torch.float32:
             return False
         if getattr(p_, '_post_accumulate_grad_hooks', None) or getattr(p_, '_backward_hooks', None):
             return False
@@ -653,7 +703,8 @@ class StackFn(torch.autograd.Function):
             tot = sum(shared_n + ((n_ - 11) // 4) * exp_n for (_, n_) in spans)
             # no memset of the weight-gradient matrices: the deferred launches WRITE them (wgrad_store); only the vector
             # gradients (accumulated with atomics by the column folds) are zeroed, in one multi-tensor fill
-            whole = None        # allocated when the first block needs fresh gradient storage
+            whole = None        # allocated when the first group needs fresh gradient storage
+            reg = _task_flats()
         grads_all = [None] * len(params)
         goff = 0
         store_ok, acquired = WGRAD_STORE, []      # (flat, fresh, is_expert) of every gradient bucket of the pass
@@ -672,26 +723,49 @@ class StackFn(torch.autograd.Function):
                 store_ok = store_ok and all(fr for _, fr in got)      # a bucket an earlier pass of the step already fed: accumulate
                 acquired += [(f_, fr, j > 0) for j, (f_, fr) in enumerate(got)]
             else:
-                have = _existing_flats(params[o:o + n_], shared_n, exp_n, nexp) if INPLACE_ACCUM else None
-                reused = have is not None and _same_views(params[o:o + n_], _fill_grads(D, have, d, hid, nexp))
-                if reused:
-                    # the block's parameters hold this layout already: accumulate in place, nothing to hand to autograd
-                    flats = have
+                bp = params[o:o + n_]
+                groups = [(bp[:11], shared_n)] + [(bp[11 + 4 * e: 15 + 4 * e], exp_n) for e in range(nexp)]
+                ni = ctx.needs_input_grad[2 + o: 2 + o + n_]
+                flats, kept = [], []
+                for gi, (gp_, gn_) in enumerate(groups):
+                    lo = 0 if gi == 0 else 11 + 4 * (gi - 1)
+                    wanted = all(w or not p_.requires_grad for p_, w in zip(gp_, ni[lo:lo + len(gp_)]))
+                    have, how = None, 0
+                    if INPLACE_ACCUM and wanted:
+                        if reg is not None and _group_key(gp_) in reg:
+                            have, how = reg[_group_key(gp_)], 1                     # an earlier node of this backward
+                        elif _INTO_GRAD[0]:
+                            # an earlier backward of this step: only when the parameters hold exactly this layout's views
+                            have = _grad_flat(gp_, gn_)
+                            lay = (shared_layout(gp_, d) if gi == 0 else expert_layout(gp_, d, hid)) if have is not None else None
+                            if have is not None and _same_views(lay, have):
+                                how = 2
+                            else:
+                                have = None
+                    flats.append(have)
+                    kept.append(how)
+                for gi, (gp_, gn_) in enumerate(groups):
+                    if flats[gi] is None:
+                        if whole is None:
+                            whole = torch.empty(tot, dtype=f32, device=dev) if WGRAD_STORE else torch.zeros(tot, dtype=f32, device=dev)
+                        flats[gi] = whole[goff:goff + gn_]
+                        lo = 0 if gi == 0 else 11 + 4 * (gi - 1)
+                        if reg is not None and INPLACE_ACCUM and all(w or not p_.requires_grad for p_, w in zip(gp_, ni[lo:lo + len(gp_)])):
+                            reg[_group_key(gp_)] = flats[gi]
+                    goff += gn_
+                    acquired.append((flats[gi], kept[gi] == 0, gi > 0))
+                if any(kept):
                     store_ok = False
-                    goff += shared_n + nexp * exp_n
-                    acquired += [(f_, False, j > 0) for j, f_ in enumerate(flats)]
-                else:
-                    if whole is None:
-                        whole = torch.empty(tot, dtype=f32, device=dev) if WGRAD_STORE else torch.zeros(tot, dtype=f32, device=dev)
-                    flats = [whole[goff:goff + shared_n]]
-                    goff += shared_n
-                    for e in range(nexp):
-                        flats.append(whole[goff:goff + exp_n])
-                        goff += exp_n
-                    acquired += [(f_, True, j > 0) for j, f_ in enumerate(flats)]
             grads = _fill_grads(D, flats, d, hid, nexp)
-            if sink is not None or not reused:
+            if sink is not None:
                 grads_all[o:o + n_] = grads
+            else:
+                # groups accumulated in place hand nothing to autograd
+                for gi in range(len(groups)):
+                    lo = 0 if gi == 0 else 11 + 4 * (gi - 1)
+                    hi = 11 if gi == 0 else lo + 4
+                    if not kept[gi]:
+                        grads_all[o + lo:o + hi] = grads[lo:hi]
             _split_backward_attention(D, metas[i])
             st_ = k % nsets
             pb = tb.data_ptr() + st_ * 11 * md * 2

@@ -39,6 +39,7 @@ class BlockDesc(ctypes.Structure):
         [('M', _i32), ('d', _i32), ('hidden', _i32), ('heads', _i32),
          ('n_experts', _i32), ('exp_row0', _i32 * 2), ('exp_rows', _i32 * 2),
          ('n_attn', _i32), ('nseq', _i32 * 2), ('maxlen', _i32 * 2), ('lse_stride', _i32 * 2),
+         ('attn_seed_idx', _i32 * 2), ('attn_seq0', _i32 * 2),
          ('seg', _fp * 2), ('keymask', _fp), ('eps', _f32),
          ('drop_thresh', _u32), ('attn_drop_thresh', _u32), ('inv_keep', _f32), ('attn_inv_keep', _f32),
          ('seed', _u64), ('rs1', _fp), ('rs2', _fp), ('row_index', _fp), ('tile', _i32), ('need_bwd', _i32)]
@@ -83,9 +84,9 @@ _SIGS = {
     'vlmo_ln_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _f32, _u64,
                           _i32, _i32, _vp, _i64, _vp],
     'vlmo_attn_fwd': [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _f32,
-                      _u64, _vp],
+                      _u64, _i32, _vp],
     'vlmo_attn_bwd': [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
-                      _u32, _f32, _u64, _vp],
+                      _u32, _f32, _u64, _i32, _vp],
     'vlmo_resid_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _f32, _u64, _vp, _i64, _vp],
     'vlmo_colsum': [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp],
     'vlmo_cast_weight': [_i32, _vp, _i32, _i32, _vp, _vp, _vp],
@@ -133,7 +134,7 @@ _SIGS = {
 }
 
 _lib = None
-ABI_VERSION = 4      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
+ABI_VERSION = 5      # vlmo_abi_version(): struct layouts of include/vlmo_hip.h mirrored above
 
 def lib():
     """Load (once) and return the C-ABI library; raise loudly if it is missing."""
@@ -295,18 +296,18 @@ def ln_resid_bwd(dy, x, w, mean, rstd, dres, dx, dw, db, zd, gamma, row_scale, r
     _check(rc, 'vlmo_ln_resid_bwd')
 
 
-def attn_fwd(qkv, seg, nseq, keymask, ctx, lse, heads, d, max_len, scale, drop=(0, 1.0), seed=0):
+def attn_fwd(qkv, seg, nseq, keymask, ctx, lse, heads, d, max_len, scale, drop=(0, 1.0), seed=0, mask_seq0=0):
     rc = lib().vlmo_attn_fwd(_p(qkv), _p(seg), nseq, _p(keymask), _p(ctx), _p(lse),
                              lse.stride(0) if lse is not None else 0, heads, d, max_len, scale,
-                             drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF, _stream())
+                             drop[0], drop[1], seed & 0xFFFFFFFFFFFFFFFF, mask_seq0, _stream())
     _check(rc, 'vlmo_attn_fwd')
 
 
 def attn_bwd(qkv, ctx, dctx, lse, seg, nseq, keymask, dqkv, heads, d, max_len, scale,
-             drop=(0, 1.0), seed=0, qv_colsum=None):
+             drop=(0, 1.0), seed=0, qv_colsum=None, mask_seq0=0):
     rc = lib().vlmo_attn_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), lse.stride(0), _p(seg), nseq,
                              _p(keymask), _p(dqkv), _p(qv_colsum), heads, d, max_len, scale, drop[0], drop[1],
-                             seed & 0xFFFFFFFFFFFFFFFF, _stream())
+                             seed & 0xFFFFFFFFFFFFFFFF, mask_seq0, _stream())
     _check(rc, 'vlmo_attn_bwd')
 
 

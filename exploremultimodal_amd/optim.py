@@ -245,7 +245,10 @@ class NativeScalerWithGradNormCount:
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         if self.reducer is not None:
             self.reducer.prepare(loss)
-        loss.backward(create_graph=create_graph)
+        from . import engine
+        # an ordinary accumulating backward(): a micro-step may add straight into the gradient views the parameters hold
+        with engine.accumulate_into_grad(not create_graph):
+            loss.backward(create_graph=create_graph)
         if self.reducer is not None:
             self.reducer.finish(accumulate=not update_grad)
         if not update_grad:

@@ -156,17 +156,19 @@ int vlmo_ln_resid_bwd(const void* dy, const float* x, const float* w, const floa
 /* Fused softmax attention over packed rows (vlmo.py:79-95).
  * qkv [M, 3*d] (q | k | v, head-major inside each third), ctx [M, d].
  * seg[s] = {rowA, lenA, rowB, lenB}: sequence s = rows [rowA,rowA+lenA) ++ [rowB,rowB+lenB).
- * keymask [M] int32 (0 = padded key, vlmo.py:89-91) or NULL.  lse [S, heads, NPAD] fp32. */
+ * keymask [M] int32 (0 = padded key, vlmo.py:89-91) or NULL.  lse [S, heads, NPAD] fp32.
+ * Attention dropout (vlmo.py:93) is a counter hash of (seed, mask_seq0 + s, head, query, key): a backward launch over
+ * the sequences [s0, s0 + n) of a forward launch passes mask_seq0 = s0 and the forward's seed to regenerate its mask. */
 int vlmo_attn_fwd(const void* qkv, const int32_t* seg, int num_seq, const int32_t* keymask,
                   void* ctx, float* lse, int lse_stride, int heads, int d, int max_len,
-                  float scale, uint32_t drop_thresh, float inv_keep, uint64_t seed,
+                  float scale, uint32_t drop_thresh, float inv_keep, uint64_t seed, int mask_seq0,
                   hipStream_t stream);
 /* qv_colsum (optional, [num_seq][2 d] fp32, written): per sequence the column sums of its tokens' dq | dv rows -- the
  * q_bias / v_bias gradient (vlmo.py:71-75) is their sum over the sequences, so nobody re-reads dqkv for it. */
 int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                   int lse_stride, const int32_t* seg, int num_seq, const int32_t* keymask,
                   void* dqkv, float* qv_colsum, int heads, int d, int max_len, float scale,
-                  uint32_t drop_thresh, float inv_keep, uint64_t seed, hipStream_t stream);
+                  uint32_t drop_thresh, float inv_keep, uint64_t seed, int mask_seq0, hipStream_t stream);
 
 /* Residual-branch backward (vlmo.py:194-196): dz = dx * gamma * row_scale * dropmask/(1-p);
  * dgamma += sum_m dx * row_scale * zd;  dbias += sum_m dz. */
@@ -282,6 +284,8 @@ typedef struct VlmoBlockDesc {
     int32_t M, d, hidden, heads;
     int32_t n_experts, exp_row0[2], exp_rows[2];   /* 1..2 experts */
     int32_t n_attn, nseq[2], maxlen[2], lse_stride[2];
+    int32_t attn_seed_idx[2], attn_seq0[2];         /* dropout mask of launch a: seed + 11 + attn_seed_idx[a], first sequence attn_seq0[a]
+                                                     * (a backward launch split off a shared forward launch keeps the forward's mask) */
     const int32_t* seg[2];
     const int32_t* keymask;
     float eps;

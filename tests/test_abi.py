@@ -25,7 +25,7 @@ def test_library_exports_header_symbols():
         assert hasattr(L, n), f'{n} declared in vlmo_hip.h but not exported'
     assert sorted(hip.exported_symbols()) == names, 'hip.py binding list and header disagree'
     L.vlmo_abi_version.restype = ctypes.c_int
-    assert L.vlmo_abi_version() == 4
+    assert L.vlmo_abi_version() == hip.ABI_VERSION == 5
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -279,6 +279,36 @@ def test_native_stack_path_equals_per_block_path(preset, B):
         assert (gs[n] - gb[n]).abs().max().item() <= tol, (n, (gs[n] - gb[n]).abs().max().item(), tol)
 
 
+@pytest.mark.parametrize('stack', [True, False])
+def test_split_backward_attention_regenerates_the_forward_dropout_mask(stack):
+    """Below the fusion layer text and image sequences share ONE forward attention launch and the backward runs as two
+    right-sized launches (engine._split_backward_attention).  With attention dropout on (vlmo.py:93; 0.1 in every
+    reference config) the text launch must regenerate the mask of ITS sequences of the shared forward launch
+    (VlmoBlockDesc.attn_seq0 / attn_seed_idx): gradients with the split on and off agree to summation-order
+    rounding.  (Round 3 shipped the split with the text launch keyed as a second launch: a different mask.)"""
+    from exploremultimodal_amd import engine
+    model, mc = build('small', drop=0.1)
+    model.train()
+    B = 5
+    batch = synth.synth_batch(mc, B, seed=78)
+    kw = modes(mc, batch, B)['vl']
+    R = torch.randn(B, mc.max_text_len + synth.num_img_tokens(mc), mc.embed_dim, device=DEV)
+    old = engine.USE_STACK, engine.SPLIT_BWD_ATTENTION
+    try:
+        engine.USE_STACK = stack
+        engine.SPLIT_BWD_ATTENTION = True
+        xs, gs = _vl_step(model, kw, R, 3)
+        engine.SPLIT_BWD_ATTENTION = False
+        xb, gb = _vl_step(model, kw, R, 3)
+    finally:
+        engine.USE_STACK, engine.SPLIT_BWD_ATTENTION = old
+    assert torch.equal(xs, xb)
+    assert set(gs) == set(gb)
+    for n in gb:
+        tol = 1e-3 * gb[n].abs().max().item() + 1e-9
+        assert (gs[n] - gb[n]).abs().max().item() <= tol, (n, (gs[n] - gb[n]).abs().max().item(), tol)
+
+
 @pytest.mark.parametrize('preset,B,out_tol,mean_tol,grad_tol', [('base', 64, 3e-2, 4e-3, 5e-2),
                                                                 ('large', 32, 4.5e-2, 6e-3, 8e-2)])
 def test_full_batch_against_oracle(preset, B, out_tol, mean_tol, grad_tol):
@@ -332,9 +362,12 @@ def test_full_batch_against_oracle(preset, B, out_tol, mean_tol, grad_tol):
 
 
 def test_second_backward_accumulates_in_place():
-    """A second backward pass over parameters that already hold the engine's gradient views (another objective of the
-    step, or a gradient-accumulation micro-step; multimodal.py:260,316-323) adds into them inside the weight-gradient
-    kernels: same storage afterwards, values = sum of the two passes."""
+    """A second backward() over parameters that already hold the engine's gradient views (a gradient-accumulation
+    micro-step; multimodal.py:260,316-323) adds into them inside the weight-gradient kernels when the loop opts in with
+    engine.accumulate_into_grad() (the package's NativeScalerWithGradNormCount does): same storage afterwards,
+    values = sum of the two passes.  Decided per parameter GROUP: an image-only pass after a VL pass reuses the shared
+    groups and the image experts it already fed and hands autograd fresh tensors only for experts seen the first time."""
+    from exploremultimodal_amd import engine
     model, mc = build('mini')
     model.eval()
     batch = synth.synth_batch(mc, 3, seed=5)
@@ -343,7 +376,8 @@ def test_second_backward_accumulates_in_place():
 
     def run(mode, scale):
         x, _ = model.forward_features(**kw[mode])
-        (x.float().square().mean() * scale).backward()
+        with engine.accumulate_into_grad():
+            (x.float().square().mean() * scale).backward()
 
     run('vl', 1.0)
     torch.cuda.synchronize()
@@ -358,9 +392,71 @@ def test_second_backward_accumulates_in_place():
         assert p.grad.data_ptr() == ptr                         # accumulated in place, not replaced by autograd's sum
         ref = 3.0 * g1
         assert torch.allclose(p.grad, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item() + 1e-12)
-    # an image-only pass touches the image experts and the shared parameters only: text-expert gradients stay as they are
-    before = {id(p): p.grad.clone() for p in blk if p.grad is not None}
+    # an image-only pass touches the image experts and the shared parameters only: text-expert gradients stay as they are,
+    # and every group that already had a gradient keeps its storage (per-group reuse)
+    before = {id(p): (p.grad.data_ptr(), p.grad.clone()) for p in blk if p.grad is not None}
     run('v', 1.0)
     torch.cuda.synchronize()
-    changed = sum(int(not torch.equal(p.grad, before[id(p)])) for p in blk if id(p) in before)
+    changed = sum(int(not torch.equal(p.grad, before[id(p)][1])) for p in blk if id(p) in before)
     assert 0 < changed < len(before)      # (the image experts of the fusion layers get their first gradient here)
+    assert all(p.grad.data_ptr() == before[id(p)][0] for p in blk if id(p) in before)
+    # without the opt-in a further backward() leaves the accumulation to autograd: values still add up
+    snap = {id(p): p.grad.clone() for p in blk if p.grad is not None}
+    x, _ = model.forward_features(**kw['v'])
+    x.float().square().mean().backward()
+    torch.cuda.synchronize()
+    moved = sum(int(not torch.equal(p.grad, snap[id(p)])) for p in blk if id(p) in snap)
+    assert moved > 0
+
+
+def _three_pass_loss(model, kw):
+    xv, _ = model.forward_features(**kw['v'])
+    xl, _ = model.forward_features(**kw['l'])
+    xvl, _ = model.forward_features(**kw['vl'])
+    return xv.float().square().mean() + 2.0 * xl.float().square().mean() + 3.0 * xvl.float().square().mean()
+
+
+def test_passes_of_one_backward_accumulate_in_place():
+    """V -> L -> VL passes of ONE step (the merged four-objective step, objectives.py:40-314) summed into one loss and
+    ONE backward(): the first StackFn node that reaches a parameter group returns its gradient buffer, the later nodes
+    of the same graph task add into it inside the weight-gradient kernels and return nothing (engine._task_flats), so
+    autograd has nothing to add.  Gradients equal those of the unfused path (VLMO_INPLACE_ACCUM off: one fresh tensor
+    per pass, summed by autograd) to summation-order rounding -- under backward() AND under autograd.grad(), which
+    must not touch .grad at all."""
+    from exploremultimodal_amd import engine
+    model, mc = build('mini')
+    model.eval()
+    batch = synth.synth_batch(mc, 3, seed=6)
+    kw = modes(mc, batch, 3)
+    names = [n for n, p in model.named_parameters() if 'blocks.' in n]
+    blk = [p for n, p in model.named_parameters() if 'blocks.' in n]
+
+    def grads(inplace, use_grad_api):
+        old = engine.INPLACE_ACCUM
+        engine.INPLACE_ACCUM = inplace
+        try:
+            for p in model.parameters():
+                p.grad = None
+            loss = _three_pass_loss(model, kw)
+            if use_grad_api:
+                used = [p for p in blk]
+                out = torch.autograd.grad(loss, used, allow_unused=True)
+                assert all(p.grad is None for p in model.parameters())         # autograd.grad leaves .grad alone
+                res = {n: g.clone() for n, g in zip(names, out) if g is not None}
+            else:
+                loss.backward()
+                res = {n: p.grad.clone() for n, p in zip(names, blk) if p.grad is not None}
+            torch.cuda.synchronize()
+            return res
+        finally:
+            engine.INPLACE_ACCUM = old
+
+    ref = grads(False, False)
+    for api in (False, True):
+        got = grads(True, api)
+        assert set(got) == set(ref)
+        for n in ref:
+            tol = 2e-3 * ref[n].abs().max().item() + 1e-9
+            assert (got[n] - ref[n]).abs().max().item() <= tol, (api, n, (got[n] - ref[n]).abs().max().item(), tol)
+    # the in-place path really ran: the second and third pass found the first pass's buffers
+    assert engine._TASK_FLATS['flats'], 'no gradient buffer was registered for the graph task'
