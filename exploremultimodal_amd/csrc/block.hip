@@ -339,9 +339,10 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D, const
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
-        // fc1 bias gradient: the DGELU epilogue leaves column sums per 32-row block behind the (4 + experts) fold
-        // slots when the workspace has room; they join the block's other column folds.  Else: a pass over du.
-        const int nblk64 = (n + 31) / 32;       // 32-row blocks
+        // fc1 bias gradient: the DGELU epilogue leaves column-sum partials (one row per 16 output rows, see
+        // VlmoEpilogue.colpart) behind the (4 + experts) fold slots when the workspace has room; they join the block's
+        // other column folds.  Else: a pass over du.
+        const int nblk64 = (n + 15) / 16;       // 16-row blocks
         if (fold_db1 && b->db1[x] && (colpart_off + (int64_t)nblk64 * hid) * 4 <= b->ws_bytes) {
             e.colpart = (float*)b->ws_main + colpart_off;
             colpart_off += (int64_t)nblk64 * hid;

@@ -19,6 +19,8 @@
 #include <stdlib.h>
 #include <mutex>
 #include <vector>
+#include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -503,8 +505,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
             const bool more = kt + 1 < nk;
             seg_boundary(kt);
             read_half(cur, 0);
-            bar();
+            // the LDS-DMA of the next K-tile goes out in the READ segment, behind the fragment reads (round 4: in-kernel
+            // stamps showed the eight DMA instructions' issue time -- ~400 cycles -- in front of the wave's own MFMAs when
+            // they were issued at the head of the MFMA segment; here it runs beside the partner wave's MFMA segment.  The
+            // other buffer was last read two segments ago by this group and one segment ago by the other, each behind
+            // lgkmcnt(0) + barrier.)  3 273 -> 2 776 cycles per K-tile in the stamped build, +4..9 % per GEMM.
             if (more) stage((kt + 1) & 1, kt + 1);
+            bar();
             mfma_half();
             bar();
             read_half(cur, 1);
@@ -669,12 +676,286 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmNTGr
                 for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o, 64);
-                const int blk = gmb >> 5;
-                if (lane < LPR && col_ok && gmb < p.M) *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
+                // colpart has one row per 16 output rows (the 16x16x32 kernels place their passes at multiples of 16):
+                // this 32-row pass owns two of them, the sums go to the first, zeros to the second
+                const int blk = gmb >> 4;
+                if (lane < LPR && col_ok && gmb < p.M) {
+                    *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
+                    if (gmb + 16 < p.M) *(f32x4*)(p.e.colpart + (size_t)(blk + 1) * p.N + gn) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 csum = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
+}
+
+// ------------------------------------------------ NT, 16x16x32 MFMA, tile height as a parameter ---
+// Same LDS image, staging, ping-pong schedule and epilogue arithmetic as gemm_nt_kernel<..., PP>, with two differences:
+//  * v_mfma_f32_16x16x32_bf16: at equal cycles per flop the chip holds a higher clock on this shape than on 32x32x16
+//    (MI355X guide, DVFS give-back item 7: 1.12-1.15x the FLOP/s of the 32x32x16 loop on random data).  Fragment
+//    reads are ds_read_b128 of 16 rows x 4 k-chunks out of the unchanged swizzled [rows][64] image
+//    (tests/test_lds_layouts.py::test_gemm_nt16_fragments: right elements, conflict-free).
+//  * the workgroup tile is (32 * TM) x 256: eight waves as 2 x 4, a wave owns TM x 4 accumulator tiles of 16 x 16, so the
+//    tile HEIGHT moves in 32-row steps (TM = 6 .. 10: 192 .. 320 rows).  M = 16 704 = 65.25 x 256 puts every N = 3 072
+//    GEMM of VLMo-Base at 64 pairs a few tiles into a fourth dispatch round of 256-row tiles; 288 rows = 58 x 12 tiles =
+//    2.7 rounds, 320 rows for N = 2 304 = 53 x 9 = 1.9 rounds, 224 rows for N = 768 = 75 x 3 = 225 of 256 CUs.
+template <int... Is, typename F> __device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// (A two-per-CU variant of this kernel -- four waves, (32 * TM) x 128 tile on 32-deep slices, the epilogue of one workgroup
+// under the K loop of the other -- was built and measured in round 4: 256 rows = the 256x128x32 tile of gemm_nt_kernel
+// (121 vs 122 us for fc1), 288 rows 125 us against 116 us for this kernel at 288 rows: the 256-row build fits THREE
+// workgroups per CU (168 registers), the 288-row one two.  Removed.)
+template <typename T, int TM, int EPI, int SCHED = 1>
+__global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp) {
+    typedef typename Elem<T>::v8 v8;
+    constexpr int BM = 32 * TM, WN = 4, BN = WN * 64, BK = 64, NW = 2 * WN, WROWS = 16 * TM;
+    constexpr int ROWB = BK * 2, SRPI = 1024 / ROWB, CPR = ROWB / 16;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NAI = BM / SRPI;                                  // A staging instructions per K-tile, whole workgroup
+    constexpr int NA = (NAI + NW - 1) / NW, NB = BN / SRPI / NW;    // ... per wave (the last A one only on waves < NAI % NW)
+    static_assert(NW * 32 * 64 * 4 <= 2 * STAGE, "epilogue LDS must fit in the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int la = xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_GROUPS; ++q)
+        if (q < gp.ngroups && la >= gp.t0[q]) gi = q;
+    gi = __builtin_amdgcn_readfirstlane(gi);
+    // the chosen problem in SGPRs (see gemm_nt_kernel)
+    GemmNT p;
+    {
+        const GemmNT& gq = gp.g[gi];
+        p.A = uniform_ptr(gq.A), p.B = uniform_ptr(gq.B);
+        p.M = uniform_i(gq.M), p.N = uniform_i(gq.N), p.K = uniform_i(gq.K), p.lda = uniform_i(gq.lda), p.ldb = uniform_i(gq.ldb);
+        p.group_m = uniform_i(gq.group_m);
+        p.e.out = (void*)uniform_ptr(gq.e.out), p.e.out2 = (void*)uniform_ptr(gq.e.out2);
+        p.e.bias = (const float*)uniform_ptr(gq.e.bias), p.e.gamma = (const float*)uniform_ptr(gq.e.gamma);
+        p.e.resid = (const float*)uniform_ptr(gq.e.resid), p.e.row_scale = (const float*)uniform_ptr(gq.e.row_scale);
+        p.e.row_index = (const int32_t*)uniform_ptr(gq.e.row_index), p.e.aux = uniform_ptr(gq.e.aux);
+        p.e.ldo = uniform_i(gq.e.ldo), p.e.ld2 = uniform_i(gq.e.ld2), p.e.relu = uniform_i(gq.e.relu);
+        p.e.drop_thresh = (uint32_t)uniform_i((int)gq.e.drop_thresh);
+        p.e.inv_keep = uniform_f(gq.e.inv_keep), p.e.beta = uniform_f(gq.e.beta);
+        p.e.seed = (uint64_t)uniform_ptr((const void*)gq.e.seed);
+        p.e.colpart = (float*)uniform_ptr(gq.e.colpart);
+    }
+    int m0, n0;
+    {
+        const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+        const int lid = la - uniform_i(gp.t0[gi]);
+        const int gm_ = p.group_m > 0 ? p.group_m : 1;
+        const int per_group = gm_ * tiles_n;
+        const int first_m = (lid / per_group) * gm_;
+        const int gsz = min(tiles_m - first_m, gm_);
+        const int in_g = lid % per_group;
+        m0 = (first_m + in_g % gsz) * BM;
+        n0 = (in_g / gsz) * BN;
+    }
+    // staging sources: a wave-uniform 64-bit base (the tile's first row, advanced by 128 bytes per K-tile on the scalar
+    // unit) + one 32-bit byte offset per lane and instruction -- half the address registers of per-lane pointers,
+    // which the 320-row tile (160 accumulator registers) needs
+    const char* a_base = (const char*)p.A + (size_t)m0 * p.lda * 2;
+    const char* b_base = (const char*)p.B + (size_t)n0 * p.ldb * 2;
+    uint32_t a_off[NA], b_off[NB];
+    auto chunk_of = [&](int rr) { return (lane % CPR) ^ nt_swz<64>(rr); };
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int rr = (i * NW + wave) * SRPI + lane / CPR;
+        const int gr = min(m0 + rr, p.M - 1) - m0;
+        a_off[i] = (uint32_t)((gr * p.lda + chunk_of(rr) * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int rr = (i * NW + wave) * SRPI + lane / CPR;
+        const int gr = min(n0 + rr, p.N - 1) - n0;
+        b_off[i] = (uint32_t)((gr * p.ldb + chunk_of(rr) * 8) * 2);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* s = smem + buf * STAGE;
+        const char* ab = a_base + (size_t)kt * ROWB;
+        const char* bb = b_base + (size_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if ((i + 1) * NW <= NAI || i * NW + wave < NAI) glds16(ab + a_off[i], s + (i * NW + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(bb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
+    };
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int swz = (l15 >> 1) & 7;                 // nt_swz of the lane's row: row origins are multiples of 16
+    const int a_row_off = (wm * WROWS + l15) * ROWB;
+    const int b_row_off = A_BYTES + (wn * 64 + l15) * ROWB;
+    const int nk = p.K / BK;
+
+    stage(0, 0);
+    {
+        // ping-pong schedule of gemm_nt_kernel<PP>: per K-tile  read k-half 0 | MFMAs | read k-half 1 | MFMAs,  the wm == 1
+        // waves one segment behind the wm == 0 waves; a k-half is ONE 32-deep MFMA step here
+        v8 af[TM], bf[4];
+        auto read_half = [&](const char* s_, int hf) {
+            const int coff = ((4 * hf + g4) ^ swz) << 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *(const v8*)(s_ + b_row_off + j * 16 * ROWB + coff);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const v8*)(s_ + a_row_off + i * 16 * ROWB + coff);
+        };
+        auto mfma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mfma16(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) bar();
+        // diagnostic build (SCHED & 8): s_memtime at every segment boundary of one K loop, sums per segment kind and the
+        // in-kernel clock (cycles per 100 MHz tick of s_memrealtime) -> e.colpart[workgroup][wave][8] (tools/nt16_probe.py)
+        constexpr bool PROBE = (SCHED & 8) != 0;
+        constexpr int SCH = SCHED & 7;
+        uint64_t seg_sum[4] = {0, 0, 0, 0}, t_prev = 0, t_begin = 0, r_begin = 0;
+        auto stamp = [&](int k) {
+            if constexpr (PROBE) {
+                const uint64_t t = __builtin_amdgcn_s_memtime();
+                seg_sum[k] += t - t_prev;
+                t_prev = t;
+            }
+        };
+        if constexpr (PROBE) {
+            t_begin = t_prev = __builtin_amdgcn_s_memtime();
+            r_begin = __builtin_amdgcn_s_memrealtime();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* cur = smem + (kt & 1) * STAGE;
+            const bool more = kt + 1 < nk;
+            read_half(cur, 0);
+            // SCHED 1: the LDS-DMA of the next K-tile is issued in the READ segment, behind the fragment reads (the other
+            // buffer was last read two segments ago by this group, one segment ago by the other, each behind lgkmcnt(0) +
+            // barrier): the issue cost of the eight DMA instructions (~60-180 cycles each) then runs beside the partner
+            // wave's MFMA segment instead of in front of this wave's own
+            if (SCH == 1 && more) stage((kt + 1) & 1, kt + 1);
+            bar();
+            stamp(0);
+            if (SCH == 0 && more) stage((kt + 1) & 1, kt + 1);
+            mfma_half();
+            bar();
+            stamp(1);
+            read_half(cur, 1);
+            if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+            stamp(2);
+            mfma_half();
+            if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+            stamp(3);
+        }
+        if (wm == 0) bar();
+        if constexpr (PROBE) {
+            const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+            if (p.e.colpart && lane == 0) {
+                uint64_t* o = (uint64_t*)p.e.colpart + ((size_t)blockIdx.x * NW + wave) * 8;
+                o[0] = seg_sum[0], o[1] = seg_sum[1], o[2] = seg_sum[2], o[3] = seg_sum[3];
+                o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)nk, o[7] = (uint64_t)__builtin_amdgcn_s_getreg(0xf814) /* XCC_ID */;
+            }
+        }
+    }
+
+    // ---- epilogue: accumulators -> wave-private LDS -> full-row segments, in passes of two 16-row tiles (one for the last
+    // tile of an odd TM); the arithmetic is gemm_nt_kernel's (epilogue4 / epilogue_ext)
+    __syncthreads();
+    constexpr int ROWF = 64, LPR = 16, RPI = 4;
+    float* ep = (float*)(smem + wave * (32 * ROWF * 4));
+    const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+    const int gn = n0 + wn * 64 + rcol;
+    const bool col_ok = gn < p.N;
+    const int gnc = col_ok ? gn : 0;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
+    if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
+    if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
+    auto epi_pass = [&](auto nr_c, auto i0_c) __attribute__((always_inline)) {
+        constexpr int NR = decltype(nr_c)::value, I0 = decltype(i0_c)::value;
+        constexpr int NIT = NR * 16 / RPI;
+        const int gmb = __builtin_amdgcn_readfirstlane(m0 + wm * WROWS + I0 * 16);
+        const int gmbc = min(gmb, p.M - 1);
+        f32x4 ext[NIT];
+        float rs[NIT];
+        int ridx[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int gmc = gmbc + min(it * RPI + rrow, p.M - 1 - gmbc);
+            ridx[it] = (EPI == EPI_RESID && p.e.row_scale && p.e.row_index) ? p.e.row_index[gmc] : gmc;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
+            ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
+            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
+        }
+        // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register
+#pragma unroll
+        for (int ii = 0; ii < NR; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(ii * 16 + 4 * g4 + r) * ROWF + j * 16 + l15] = acc[I0 + ii][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = *(const f32x4*)(ep + (it * RPI + rrow) * ROWF + rcol);
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + rrow;
+            const bool ok = gmb + row < p.M && col_ok;
+            const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
+            if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) csum[j] += ok ? w[j] : 0.f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (EPI == EPI_DGELU) {
+            // column sums of this pass -> colpart row of its FIRST 16-row block, zeros to the second one's (every row of
+            // colpart[ceil(M/16)] has exactly one writer, whatever the tile height)
+            if (p.e.colpart) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o, 64);
+                const int blk = gmb >> 4;
+                if (lane < LPR && col_ok && gmb < p.M) {
+                    *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
+                    if (NR == 2 && gmb + 16 < p.M) *(f32x4*)(p.e.colpart + (size_t)(blk + 1) * p.N + gn) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    static_for(std::make_integer_sequence<int, TM / 2>{}, [&](auto pi) __attribute__((always_inline)) {
+        epi_pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * decltype(pi)::value>{});
+    });
+    if constexpr (TM & 1) epi_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, TM - 1>{});
 }
 
 // ------------------------------------------------------------------ wgrad ---
@@ -690,6 +971,11 @@ struct GemmTN {
                      // tile: no K split), 2 = C = alpha * acc
 };
 enum { TN_ATOMIC = 0, TN_ACCUM = 1, TN_STORE = 2 };
+
+#ifndef VLMO_TN_DMA_IN_READ
+#define VLMO_TN_DMA_IN_READ 1
+#endif
+constexpr bool TN_DMA_IN_READ = VLMO_TN_DMA_IN_READ != 0;      // build-time A/B (make EXTRA=-DVLMO_TN_DMA_IN_READ=0)
 
 // 256 zero bytes: the staging source of token rows past the end of the reduction dimension
 __device__ __attribute__((aligned(256))) char tn_zero_page[256];
@@ -864,8 +1150,9 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             const bool more = kt + 1 < kt1;
             read_step(cur, kt, 0, af[0], bf[0]);
             read_step(cur, kt, 1, af[1], bf[1]);
+            if (TN_DMA_IN_READ && more) stage((kt - kt0 + 1) & 1, kt + 1);      // see gemm_nt_kernel: DMA issue beside the partner's MFMAs
             bar();
-            if (more) stage((kt - kt0 + 1) & 1, kt + 1);
+            if (!TN_DMA_IN_READ && more) stage((kt - kt0 + 1) & 1, kt + 1);
             mfma_half();
             bar();
             read_step(cur, kt, 2, af[0], bf[0]);
@@ -1057,6 +1344,47 @@ int launch_nt(int epi, GemmNTGroups& p, hipStream_t st) {
     return 0;
 }
 
+// 16x16x32 kernels: (32 * TM) x 256 tiles, one workgroup per CU
+template <typename T, int TM, int SCHED = 1, unsigned EMASK = 0xFu>
+int launch_nt16(int epi, GemmNTGroups& p, hipStream_t st) {
+    constexpr int BM = 32 * TM, BN = 256, BK = 64;
+    int tiles = 0;
+    for (int q = 0; q < p.ngroups; ++q) {
+        p.t0[q] = tiles;
+        tiles += ((p.g[q].M + BM - 1) / BM) * ((p.g[q].N + BN - 1) / BN);
+    }
+    for (int q = p.ngroups; q <= MAX_GROUPS; ++q) p.t0[q] = tiles;
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    dim3 grid(tiles), block(512);
+    bool known = true;
+#define VLMO_LAUNCH16(E)                                                                        \
+    case E:                                                                                     \
+    if constexpr (((EMASK >> E) & 1u) == 0) {                                                   \
+        known = false;                                                                          \
+    } else {                                                                                    \
+        auto k = gemm_nt16_kernel<T, TM, E, SCHED>;                                   \
+        static DeviceOnce attr_set;                                                             \
+        if (LDS > 65536 && attr_set.first())                                                    \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                         \
+    } break;
+    switch (epi) {
+        VLMO_LAUNCH16(EPI_BIAS)
+        VLMO_LAUNCH16(EPI_BIAS_GELU)
+        VLMO_LAUNCH16(EPI_RESID)
+        VLMO_LAUNCH16(EPI_DGELU)
+        default:
+            known = false;
+    }
+#undef VLMO_LAUNCH16
+    if (!known) {
+        vlmo_set_error("vlmo_gemm_nt: this 16x16x32 tile is not built with epilogue %d", epi);
+        return -1;
+    }
+    VLMO_CHECK_LAUNCH("vlmo_gemm_nt");
+    return 0;
+}
+
 }  // namespace
 
 // ---- optional in-library timing of GEMM launches (bench.py's roofline): HIP event pairs recorded on the
@@ -1148,6 +1476,7 @@ int check_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int
 
 int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_nt: dtype must be bf16 or f16");
+    const int tile_in = tile;
     long Mtot = 0;
     for (int q = 0; q < gp.ngroups; ++q) Mtot += gp.g[q].M;
     const int N = gp.g[0].N, K = gp.g[0].K;
@@ -1181,7 +1510,51 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             if (e192 * 10 <= e256 * 9) tile = 8;
         }
     }
-    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4 or 8 (got %d)", tile);
+    // 16x16x32 tiles of (32 * TM) x 256, TM = 6 .. 10: the height is chosen so that the tiles fill whole dispatch rounds of
+    // the 256 CUs.  Cost model (tools/nt16_bench.py, M = 16 704: the measured times of one shape are proportional to it
+    // within 4 %): a launch costs rounds x tile height, rounds = ceil(tiles / 256).  The tiles picked above cost, in the same
+    // units (height 8 = 256 rows): 256x256 rounds x 8, 192x256 rounds x 6, 256x128x32 (two per CU, the epilogue of one under
+    // the K loop of the other) rounds-of-512 x 8 x 0.9, 128x128 rounds-of-512 x 4.
+    static const int nt16 = getenv("VLMO_NT16") ? atoi(getenv("VLMO_NT16")) : 1;       // measurement aid: 0 = off
+    if (nt16 && (tile == 0 || tile == 3 || tile == 4 || tile == 8) && dtype == VLMO_BF16 && !gp.g[0].k1 && !gp.g[0].ckw &&
+        (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU) && N >= 512 && K >= 512 &&
+        Mtot * (long)N >= 150l * 65536 && tile_in < 0) {
+        auto count = [&](int bm, int bn) {
+            long t = 0;
+            for (int q = 0; q < gp.ngroups; ++q) t += (long)((gp.g[q].M + bm - 1) / bm) * ((N + bn - 1) / bn);
+            return t;
+        };
+        double cur;
+        if (tile == 3) cur = (double)((count(256, 256) + 255) / 256) * 8;
+        else if (tile == 8) cur = (double)((count(192, 256) + 255) / 256) * 6;
+        else if (tile == 4) cur = (double)((count(256, 128) + 511) / 512) * 8 * 0.9;
+        else cur = (double)((count(128, 128) + 511) / 512) * 4;
+        int best = 0;
+        double bc = 1e30;
+        for (int tm = 6; tm <= 10; ++tm) {
+            const double c = (double)((count(32 * tm, 256) + 255) / 256) * tm;
+            if (c < bc) bc = c, best = tm;
+        }
+        if (bc <= cur * 0.97) tile = 100 + best;
+    }
+    if (tile >= 106 && tile <= 110) {
+        // 16x16x32 MFMA, (32 * (tile - 100)) x 256 tile: bf16, plain GEMM (no convolution, no second segment)
+        VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 are bf16, single-source");
+        ProfScope prof(epi + 16, 2.0 * Mtot * N * K, stream);
+        switch (tile) {
+            case 106: return launch_nt16<bf16, 6>(epi, gp, stream);
+            case 107: return launch_nt16<bf16, 7>(epi, gp, stream);
+            case 108: return launch_nt16<bf16, 8>(epi, gp, stream);
+            case 109: return launch_nt16<bf16, 9>(epi, gp, stream);
+            default: return launch_nt16<bf16, 10>(epi, gp, stream);
+        }
+    }
+    if (tile >= 908 && tile <= 909) {       // diagnostic: segment stamps of the 256-row kernel, schedule 0 / 1 (e.colpart = stamp buffer)
+        VLMO_CHECK_ARG(epi == EPI_BIAS, "vlmo_gemm_nt: the probe build has the bias epilogue only");
+        return tile == 908 ? launch_nt16<bf16, 8, 8, 1u>(epi, gp, stream) : launch_nt16<bf16, 8, 9, 1u>(epi, gp, stream);
+    }
+    if (tile == 208) return launch_nt16<bf16, 8, 0, 1u>(epi, gp, stream);     // measurement aid: schedule 0 (DMA issued in the MFMA segment), bias epilogue
+    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4, 8 or 106..110 (got %d)", tile);
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
     if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU))) tile = 3;
     ProfScope prof(epi + (tile == 3 || tile == 8 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);

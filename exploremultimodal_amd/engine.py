@@ -695,7 +695,7 @@ class StackFn(torch.autograd.Function):
         tb = _persist(dev, 'tb', nsets * 11 * md, torch.bfloat16)
         slot = hip.lib().vlmo_reduce_ws_bytes(2 * d)
         # column-fold slots + the du column partials of the DGELU epilogue + the attention backward's per-sequence dq | dv sums
-        ws_n = 6 * slot // 4 + (M // 32 + 3) * hid + 4 * m0.plan.B * d
+        ws_n = 6 * slot // 4 + (M // 16 + 4) * hid + 4 * m0.plan.B * d
         ws = _persist(dev, 'ws', nsets * ws_n, f32)
         dxs = _persist(dev, 'dx', 3 * md, f32)
         dx_in = torch.empty((M, d), dtype=f32, device=dev)

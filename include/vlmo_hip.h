@@ -69,9 +69,11 @@ typedef struct VlmoEpilogue {
     float inv_keep;         /* 1 / (1 - p)                                  */
     float beta;
     uint64_t seed;
-    float* colpart;         /* VLMO_EPI_DGELU: [ceil(M/32), N] fp32 or NULL: row b = column sums of  */
-                            /* the values written to out rows [32b, 32b+32) -- the fc1 bias gradient */
-                            /* is the fold of these rows (vlmo_colwork_multi kind 0); plain stores   */
+    float* colpart;         /* VLMO_EPI_DGELU: [ceil(M/16), N] fp32 or NULL: column-sum partials of   */
+                            /* the values written to out; EVERY row is written (an epilogue pass     */
+                            /* puts the sums of its 16 or 32 output rows into the row of its first   */
+                            /* 16-row block and zeros into the other) -- the fc1 bias gradient is    */
+                            /* the fold of these rows (vlmo_colwork_multi kind 0); plain stores      */
 } VlmoEpilogue;
 
 const char* vlmo_last_error(void);
@@ -81,7 +83,9 @@ int vlmo_abi_version(void);
  * (two workgroups per CU), 3 = 256x256x64 with the two-wave-group ping-pong schedule (one per CU),
  * 4 = 256x128x32 (two per CU; bf16 with the bias / bias+GELU epilogues, else it falls back to 0),
  * 8 = 192x256x64 ping-pong (bf16 with the bias / bias+GELU / residual / GELU-derivative epilogues, else 3): picked when its tile count
- * needs fewer dispatch rounds than 256x256 (VLMo-Large at 32 pairs per GPU).
+ * needs fewer dispatch rounds than 256x256 (VLMo-Large at 32 pairs per GPU),
+ * 106..110 = (32 * (tile - 100)) x 256 x 64 ping-pong on v_mfma_f32_16x16x32 (192 .. 320 rows; bf16, the same four
+ * epilogues): tile height chosen per (M, N) so that the tiles fill whole dispatch rounds of 256 CUs.
  * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm
  * Mlp fc1/fc2 (vlmo.py:141-157, 195-196), the PatchEmbed conv (vlmo.py:304) and,
  * with pre-transposed weights, their input gradients. K % 64 == 0, N % 4 == 0. */

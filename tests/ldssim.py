@@ -142,3 +142,20 @@ def nt32_stage_src(instr, lane):
 def nt32_frag_addr(row, ks, lane):
     h = lane >> 5
     return row * 64 + (((2 * ks + h) ^ ((row >> 2) & 3)) << 4)
+
+
+# ---- 16x16x32 MFMA fragments (gemm_nt16_kernel / gemm_tn16 body): lane l holds M[row l&15][k = 8*(l>>4) + j] ----
+def nt16_frag_addr(row_base, kh, lane):
+    """gemm_nt16_kernel fragment read of the 16-row block at row_base (a multiple of 16), 32-deep k-step kh (0, 1)
+    of the same [rows][64] image gemm_nt_kernel stages (nt_stage_src)."""
+    row = row_base + (lane & 15)
+    return row * 128 + (((4 * kh + (lane >> 4)) ^ ((row >> 1) & 7)) << 4)
+
+
+def tn16_tr_addr(ncol_base, ks, half, lane):
+    """transposed read for a 16x16x32 operand: 16 columns ncol_base.., token rows 32*ks + 8*(lane>>4) + 4*half + q."""
+    g, q, pp = lane >> 4, (lane >> 2) & 3, lane & 3
+    m = 32 * ks + 8 * g + 4 * half + q
+    n = ncol_base + 4 * pp
+    return m * 256 + (((n >> 3) ^ tn_swz(m)) << 4) + (n & 7) * 2
+

@@ -65,10 +65,12 @@ def test_gemm_nt_bias_bf16_and_padding_rows(tile):
     _close(out2, ref.relu(), 1 / 128, 1e-2, 'bias+relu epilogue')
 
 
-@pytest.mark.parametrize('tile', [4, 8])
+@pytest.mark.parametrize('tile', [4, 8, 106, 107, 108, 109, 110])
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 768), (4099, 2304, 768), (77, 128, 192)])
 def test_gemm_nt_tile4_small_integers(tile, M, N, K):
-    """The 256x128x32 and 192x256x64 tiles exist for a few epilogues only (bf16 output): integer operands small enough
+    """The 256x128x32 and 192x256x64 tiles and the 16x16x32-MFMA tiles 106..110 ((32 * (tile - 100)) x 256: a new fragment
+    layout, a new accumulator -> LDS map, staging with a ragged last instruction at 224 / 288 rows) exist for a few
+    epilogues only (bf16 output): integer operands small enough
     that every output is an integer below 256 in magnitude, i.e. exact in bf16 -- a fragment-layout or swizzle error of
     this tile shape shows up as a wrong integer, ragged edges in M and N included."""
     g = torch.Generator().manual_seed(M + N)
@@ -92,7 +94,8 @@ def test_gemm_nt_f16_dtype():
     _close(out, A.float() @ B.float().t(), 1 / 512, 1e-2, 'f16 gemm')
 
 
-def test_gemm_nt_gelu_resid_dgelu_epilogues():
+@pytest.mark.parametrize('tile', [-1, 107, 109, 110])
+def test_gemm_nt_gelu_resid_dgelu_epilogues(tile):
     M, N, K = 500, 384, 128
     A, B = _rand(M, K, seed=4), _rand(N, K, scale=0.15, seed=5)
     bias = _rand(N, seed=6, dtype=torch.float32) * 0.1
@@ -100,7 +103,7 @@ def test_gemm_nt_gelu_resid_dgelu_epilogues():
     # fc1: u and gelu(u)
     u = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     hh = torch.empty_like(u)
-    hip.gemm_nt(hip.EPI_BIAS_GELU, A, B, M, N, K, u, out2=hh, bias=bias)
+    hip.gemm_nt(hip.EPI_BIAS_GELU, A, B, M, N, K, u, out2=hh, bias=bias, tile=tile)
     _close(u, acc, 1 / 128, 1e-2, 'gelu.u')
     _close(hh, F.gelu(acc), 1 / 128, 1e-2, 'gelu.h')
     # residual: x + gamma * (acc + bias) * row_scale
@@ -109,27 +112,48 @@ def test_gemm_nt_gelu_resid_dgelu_epilogues():
     rs = (torch.rand(M, device=DEV) > 0.3).float() / 0.7
     xo = torch.empty(M, N, device=DEV)
     zd = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    hip.gemm_nt(hip.EPI_RESID, A, B, M, N, K, xo, out2=zd, bias=bias, gamma=gamma, resid=resid, row_scale=rs)
+    hip.gemm_nt(hip.EPI_RESID, A, B, M, N, K, xo, out2=zd, bias=bias, gamma=gamma, resid=resid, row_scale=rs, tile=tile)
     _close(zd, acc, 1 / 128, 1e-2, 'resid.zd')
     _close(xo, resid + gamma * acc * rs[:, None], 1e-3, 1e-3, 'resid.out')
     # dgelu: acc * gelu'(aux)
     aux = _rand(M, N, seed=9)
     dg = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    hip.gemm_nt(hip.EPI_DGELU, A, B, M, N, K, dg, aux=aux)
+    hip.gemm_nt(hip.EPI_DGELU, A, B, M, N, K, dg, aux=aux, tile=tile)
     a = aux.float().requires_grad_(True)
     F.gelu(a).backward(torch.ones_like(a))
     _close(dg, (A.float() @ B.float().t()) * a.grad, 1 / 128, 1e-2, 'dgelu')
-    # ... and the column sums of 32-row blocks (partials of the fc1 bias gradient) left by the same launch, all tiles
+
+
+@pytest.mark.parametrize('M', [500, 1000, 77])
+def test_gemm_nt_dgelu_column_partials(M):
+    """VlmoEpilogue.colpart: [ceil(M/16), N] fp32, EVERY row written by exactly one epilogue pass (sums of the pass's rows
+    in the row of its first 16-row block, zeros in the others), so that the fc1 bias gradient is the plain fold of the
+    rows whatever tile height ran: all tiles, ragged M."""
+    N, K = 384, 128
+    A, B = _rand(M, K, seed=4), _rand(N, K, scale=0.15, seed=5)
+    aux = _rand(M, N, seed=9)
+    a = aux.float().requires_grad_(True)
+    F.gelu(a).backward(torch.ones_like(a))
     want = (A.float() @ B.float().t()) * a.grad
-    nblk = (M + 31) // 32
-    for tile in (0, 3, 8):
-        cp = torch.full((nblk + 1, N), 2.0, device=DEV)
-        dg2 = torch.empty_like(dg)
+    nblk = (M + 15) // 16
+    ref16 = torch.stack([want[16 * b:16 * b + 16].sum(0) for b in range(nblk)])
+    for tile in (0, 3, 8, 106, 107, 108, 109, 110):
+        cp = torch.full((nblk + 1, N), float('nan'), device=DEV)
+        dg2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         hip.gemm_nt(hip.EPI_DGELU, A, B, M, N, K, dg2, aux=aux, colpart=cp, tile=tile)
-        _close(dg2, dg.float(), 1 / 128, 1e-2, 'dgelu tile')
-        ref = torch.stack([want[32 * b:32 * b + 32].sum(0) for b in range(nblk)])
-        _close(cp[:nblk], ref, 2e-3, 2e-3 * ref.abs().max().item(), f'dgelu column partials, tile {tile}')
-        assert (cp[nblk] == 2.0).all(), 'partial rows beyond ceil(M/32) were written'
+        _close(dg2, want, 1 / 128, 1e-2, 'dgelu tile')
+        assert torch.isnan(cp[nblk]).all(), f'tile {tile}: partial rows beyond ceil(M/16) were written'
+        assert not torch.isnan(cp[:nblk]).any(), f'tile {tile}: a partial row was left unwritten'
+        _close(cp[:nblk].sum(0), want.sum(0), 2e-3, 2e-3 * want.sum(0).abs().max().item(), f'fold of the partials, tile {tile}')
+        # a row is either all zeros or the sum of one or two consecutive 16-row blocks starting at its own
+        for b in range(nblk):
+            row = cp[b]
+            if (row == 0).all():
+                continue
+            one = ref16[b]
+            two = ref16[b] + (ref16[b + 1] if b + 1 < nblk else 0)
+            tol = 2e-3 * max(one.abs().max().item(), two.abs().max().item()) + 1e-6
+            assert (row - one).abs().max().item() <= tol or (row - two).abs().max().item() <= tol, (tile, b)
 
 
 def test_dropout_epilogue_consistency_with_backward():
@@ -449,7 +473,7 @@ def test_embed_txt_fwd_bwd():
         _close(got, leaf.grad, 1e-3, 1e-3, name)
 
 
-@pytest.mark.parametrize('tile', [0, 3, 4, 8])
+@pytest.mark.parametrize('tile', [0, 3, 4, 8, 107, 109])
 @pytest.mark.parametrize('epi', ['bias_gelu', 'resid'])
 def test_gemm_nt_grouped_equals_separate_launches(tile, epi):
     """vlmo_gemm_nt_grouped (the per-modality expert FFNs in one launch) is bit-identical to one launch per

@@ -110,3 +110,47 @@ def test_gemm_nt_bk32_image():
                 k0 = 16 * ks + 8 * (l >> 5)
                 np.testing.assert_array_equal(got[l], ids[row_base + (l & 31), k0:k0 + 8])
             assert S.b128_conflicts(addrs) == 1
+
+
+def test_gemm_nt16_fragments():
+    """16x16x32 operand fragments out of the SAME staged image as the 32x32x16 kernel (no new swizzle needed)."""
+    ids = _ids(128, 64)
+    lds = S.Lds(128 * 128)
+    for instr in range(16):
+        src = []
+        for lane in range(64):
+            r, c = S.nt_stage_src(instr, lane)
+            src.append(ids[r, c * 8:c * 8 + 8])
+        lds.dma16(instr * 1024, src)
+    for row_base in range(0, 128, 16):
+        for kh in range(2):
+            addrs = [S.nt16_frag_addr(row_base, kh, l) for l in range(64)]
+            got = lds.read_b128(addrs)
+            for l in range(64):
+                k0 = 32 * kh + 8 * (l >> 4)
+                np.testing.assert_array_equal(got[l], ids[row_base + (l & 15), k0:k0 + 8])
+            assert S.b128_conflicts(addrs) == 1
+
+
+def test_gemm_tn16_fragments():
+    ids = _ids(64, 128)
+    lds = S.Lds(64 * 256)
+    for instr in range(16):
+        src = []
+        for lane in range(64):
+            r, ch = S.tn_stage_src(instr, lane)
+            src.append(ids[r, ch * 8:ch * 8 + 8])
+        lds.dma16(instr * 1024, src)
+    worst = 1
+    for ncol_base in range(0, 128, 16):
+        for ks in range(2):
+            for half in range(2):
+                addrs = [S.tn16_tr_addr(ncol_base, ks, half, l) for l in range(64)]
+                got = lds.read_tr(addrs)
+                for l in range(64):
+                    n = ncol_base + (l & 15)
+                    m0 = 32 * ks + 8 * (l >> 4) + 4 * half
+                    np.testing.assert_array_equal(got[l], ids[m0:m0 + 4, n])
+                worst = max(worst, S.tr_conflicts(addrs))
+    assert worst == 1
+
