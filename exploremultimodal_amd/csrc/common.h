@@ -111,6 +111,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// buffer form of the LDS-DMA: buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds -- a wave-uniform descriptor, a wave-uniform
+// scalar byte offset (the K-tile advance) and ONE 32-bit per-lane byte offset; no vector instruction precedes the load.
+// (The descriptor type exists in the device pass only; the host pass needs the kernels' signatures, not their bodies.)
+struct BufSrc {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r;
+#endif
+    __device__ __forceinline__ void init(const void* base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+#endif
+    }
+    __device__ __forceinline__ void load16(void* lds_wave_base, uint32_t lane_off, int scalar_off) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds_wave_base), 16, lane_off, scalar_off, 0, 0);
+#endif
+    }
+};
+
 // transposed LDS read: 4x16 block of 16-bit elements, column-major into lanes
 template <typename T>
 __device__ __forceinline__ typename Elem<T>::v4 lds_tr4(const void* p);

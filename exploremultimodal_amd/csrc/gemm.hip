@@ -775,15 +775,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
         const int gr = min(n0 + rr, p.N - 1) - n0;
         b_off[i] = (uint32_t)((gr * p.ldb + chunk_of(rr) * 8) * 2);
     }
+    // buffer form of the LDS-DMA (buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds): the K-tile advance rides in the
+    // scalar offset, the per-lane part is one 32-bit register and no vector instruction precedes the load (the global_
+    // form cost a 64-bit v_lshl_add per instruction: the address pairs and ~30 cycles of issue per DMA instruction)
+    BufSrc a_rs, b_rs;
+    a_rs.init(a_base);
+    b_rs.init(b_base);
     auto stage = [&](int buf, int kt) {
         char* s = smem + buf * STAGE;
-        const char* ab = a_base + (size_t)kt * ROWB;
-        const char* bb = b_base + (size_t)kt * ROWB;
+        const int koff = kt * ROWB;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            if ((i + 1) * NW <= NAI || i * NW + wave < NAI) glds16(ab + a_off[i], s + (i * NW + wave) * 1024);
+            if ((i + 1) * NW <= NAI || i * NW + wave < NAI)
+                a_rs.load16(s + (i * NW + wave) * 1024, a_off[i], koff);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16(bb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
+        for (int i = 0; i < NB; ++i)
+            b_rs.load16(s + A_BYTES + (i * NW + wave) * 1024, b_off[i], koff);
     };
 
     f32x4 acc[TM][4];
@@ -985,17 +992,25 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row
 
 // Output tile BM x BN (multiples of 128) per workgroup of WM x WN waves; each operand's K-tile (64 token rows)
 // is staged as BM/128 resp. BN/128 side-by-side sub-images of [64 rows][128 columns] in the dual-use swizzle.
-template <typename T, int BM, int BN, int WM, int WN, bool PP = false>
+// R4 (ping-pong kernel only): the reduction is staged in 32-token SLICES through a ring of four 32 KB slots instead of
+// 64-token tiles through two 64 KB buffers.  The reduction index of this kernel is the ROW of both operands, so a slice
+// is still made of whole 256-byte row pieces (the NT kernel cannot do this: its K runs along the rows, half a K-tile is
+// half of every cache line).  Slice h + 3 is issued in the read segment of slice h -- four DMA instructions per wave
+// and segment instead of eight in every other one -- and waited for with a counted vmcnt that leaves two slices in flight.
+template <typename T, int BM, int BN, int WM, int WN, bool PP = false, bool PROBE = false, bool R4 = false>
 __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
     typedef typename Elem<T>::v8 v8;
     typedef typename Elem<T>::v4 v4;
     constexpr int NW = WM * WN;
-    constexpr int SUB = 64 * 256;                       // one sub-image
+    constexpr int SROWS = R4 ? 32 : 64;                 // token rows per staged unit
+    constexpr int SUB = SROWS * 256;                    // one sub-image
     constexpr int NSA = BM / 128, NSB = BN / 128;
     constexpr int A_BYTES = NSA * SUB, STAGE = (NSA + NSB) * SUB;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int IA = NSA * 16 / NW, IB = NSB * 16 / NW;   // LDS-DMA instructions per wave per K-tile
-    static_assert((NSA * 16) % NW == 0 && (NSB * 16) % NW == 0, "tile/wave mismatch");
+    constexpr int IPS = SROWS / 4;                      // LDS-DMA instructions per sub-image and staged unit
+    constexpr int IA = NSA * IPS / NW, IB = NSB * IPS / NW;   // ... per wave
+    static_assert((NSA * IPS) % NW == 0 && (NSB * IPS) % NW == 0, "tile/wave mismatch");
+    static_assert(!R4 || (PP && IA + IB == 4), "slice ring: ping-pong schedule, four DMA instructions per wave and slice");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1014,31 +1029,54 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
     int a_off[IA], b_off[IB], a_row[IA], b_row[IB];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        const int ii = i * NW + wave, sub = ii >> 4, row = (ii & 15) * 4 + (lane >> 4);
+        const int ii = i * NW + wave, sub = ii / IPS, row = (ii % IPS) * 4 + (lane >> 4);
         const int ch = (lane & 15) ^ tn_swz(row);
         a_row[i] = row;
         a_off[i] = min(n1_0 + sub * 128 + ch * 8, p.N1 - 8);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        const int ii = i * NW + wave, sub = ii >> 4, row = (ii & 15) * 4 + (lane >> 4);
+        const int ii = i * NW + wave, sub = ii / IPS, row = (ii % IPS) * 4 + (lane >> 4);
         const int ch = (lane & 15) ^ tn_swz(row);
         b_row[i] = row;
         b_off[i] = min(n2_0 + sub * 128 + ch * 8, p.N2 - 8);
     }
+    // Full units go out in the buffer form of the LDS-DMA (common.h BufSrc): descriptor + scalar unit offset + one fixed 32-bit
+    // lane offset, no vector instruction and no scalar load in front of the DMA.  (The pointer form below computed a 64-bit
+    // multiply-add per instruction, selected the zero page under a divergent exec mask and fetched that page's address
+    // through the GOT with s_load + s_waitcnt lgkmcnt(0) -- which also waited for the fragment reads just issued: ~450
+    // cycles per staging call in the stamped build.)  The ragged last unit keeps the pointer form.
+    const bool fits32 = (uint64_t)p.M * (uint64_t)max(p.lda, p.ldb) * 2 < 0x7FFFFFFFull;
+    BufSrc a_rs, b_rs;
+    a_rs.init(p.A);
+    b_rs.init(p.B);
+    uint32_t a_vo[IA], b_vo[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) a_vo[i] = (uint32_t)(a_row[i] * p.lda + a_off[i]) * 2u;
+#pragma unroll
+    for (int i = 0; i < IB; ++i) b_vo[i] = (uint32_t)(b_row[i] * p.ldb + b_off[i]) * 2u;
+    // kt: index of the staged unit (64-token K-tile, or 32-token slice with R4)
     auto stage = [&](int buf, int kt) {
         char* s = smem + buf * STAGE;
+        if (PP && fits32 && (kt + 1) * SROWS <= p.M) {
+            const int sa = kt * SROWS * p.lda * 2, sb = kt * SROWS * p.ldb * 2;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) a_rs.load16(s + (i * NW + wave) * 1024, a_vo[i], sa);
+#pragma unroll
+            for (int i = 0; i < IB; ++i) b_rs.load16(s + A_BYTES + (i * NW + wave) * 1024, b_vo[i], sb);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             // token rows past M (ragged last K-tile) are staged from a zero page: operand A is then exactly zero
             // there, so the K loop needs no masking (B keeps the clamped last row; 0 * finite = 0)
-            const int gr = kt * 64 + a_row[i];
+            const int gr = kt * SROWS + a_row[i];
             const T* src = gr < p.M ? (const T*)p.A + (size_t)gr * p.lda + a_off[i] : (const T*)tn_zero_page;
             glds16(src, s + (i * NW + wave) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            const int gr = min(kt * 64 + b_row[i], p.M - 1);
+            const int gr = min(kt * SROWS + b_row[i], p.M - 1);
             glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
         }
     };
@@ -1115,7 +1153,76 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             }
         }
     };
-    if constexpr (PP) {
+    if constexpr (PP && R4) {
+        static_assert(WM == 2, "ping-pong schedule needs two row groups");
+        v8 af[2][TM], bf[2][TN];
+        auto mfma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Elem<T>::mfma(af[u][i], bf[u][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const int ns = 2 * (kt1 - kt0), s0 = 2 * kt0;       // slices of this workgroup
+        // this wave's DMA of slice h + 1 has landed; slices h + 2 and h + 3 (four instructions each) may stay in flight
+        auto wait_next = [&](int h) {
+            if (h + 3 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (h + 2 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        stage(0, s0);
+        stage(1, s0 + 1);
+        if (ns > 2) stage(2, s0 + 2);
+        wait_next(-1);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) bar();
+        uint64_t seg_sum[4] = {0, 0, 0, 0}, t_prev = 0, t_begin = 0, r_begin = 0;
+        auto stamp = [&](int k) {
+            if constexpr (PROBE) {
+                const uint64_t t = __builtin_amdgcn_s_memtime();
+                seg_sum[k] += t - t_prev;
+                t_prev = t;
+            }
+        };
+        if constexpr (PROBE) {
+            t_begin = t_prev = __builtin_amdgcn_s_memtime();
+            r_begin = __builtin_amdgcn_s_memrealtime();
+        }
+        for (int h_ = 0; h_ < ns; ++h_) {
+            const char* cur = smem + (h_ & 3) * STAGE;
+            read_step(cur, 0, 0, af[0], bf[0]);
+            read_step(cur, 0, 1, af[1], bf[1]);
+            // slot (h + 3) & 3 held slice h - 1: read by this group two segments ago, by the other one segment ago
+            if (h_ + 3 < ns) stage((h_ + 3) & 3, s0 + h_ + 3);
+            if (wm == 1 && h_ + 1 < ns) wait_next(h_);
+            bar();
+            stamp((h_ & 1) * 2);
+            mfma_half();
+            if (wm == 0 && h_ + 1 < ns) wait_next(h_);
+            bar();
+            stamp((h_ & 1) * 2 + 1);
+        }
+        if (wm == 0) bar();
+        if constexpr (PROBE) {
+            const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) {
+                uint64_t* o = (uint64_t*)p.slab + ((size_t)blockIdx.x * NW + wave) * 8;
+                o[0] = seg_sum[0], o[1] = seg_sum[1], o[2] = seg_sum[2], o[3] = seg_sum[3];
+                o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)(kt1 - kt0), o[7] = 1;
+            }
+            return;
+        }
+    } else if constexpr (PP) {
         // ping-pong schedule: see gemm_nt_kernel (wm == 1 waves run one segment behind wm == 0)
         static_assert(WM == 2, "ping-pong schedule needs two row groups");
         v8 af[2][TM], bf[2][TN];
@@ -1145,6 +1252,19 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) bar();
+        // diagnostic build (PROBE): cycles per segment kind and the in-kernel clock -> p.slab[workgroup][wave][8] (uint64)
+        uint64_t seg_sum[4] = {0, 0, 0, 0}, t_prev = 0, t_begin = 0, r_begin = 0;
+        auto stamp = [&](int k) {
+            if constexpr (PROBE) {
+                const uint64_t t = __builtin_amdgcn_s_memtime();
+                seg_sum[k] += t - t_prev;
+                t_prev = t;
+            }
+        };
+        if constexpr (PROBE) {
+            t_begin = t_prev = __builtin_amdgcn_s_memtime();
+            r_begin = __builtin_amdgcn_s_memrealtime();
+        }
         for (int kt = kt0; kt < kt1; ++kt) {
             const char* cur = smem + ((kt - kt0) & 1) * STAGE;
             const bool more = kt + 1 < kt1;
@@ -1152,18 +1272,31 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             read_step(cur, kt, 1, af[1], bf[1]);
             if (TN_DMA_IN_READ && more) stage((kt - kt0 + 1) & 1, kt + 1);      // see gemm_nt_kernel: DMA issue beside the partner's MFMAs
             bar();
+            stamp(0);
             if (!TN_DMA_IN_READ && more) stage((kt - kt0 + 1) & 1, kt + 1);
             mfma_half();
             bar();
+            stamp(1);
             read_step(cur, kt, 2, af[0], bf[0]);
             read_step(cur, kt, 3, af[1], bf[1]);
             if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bar();
+            stamp(2);
             mfma_half();
             if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bar();
+            stamp(3);
         }
         if (wm == 0) bar();
+        if constexpr (PROBE) {
+            const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) {
+                uint64_t* o = (uint64_t*)p.slab + ((size_t)blockIdx.x * NW + wave) * 8;
+                o[0] = seg_sum[0], o[1] = seg_sum[1], o[2] = seg_sum[2], o[3] = seg_sum[3];
+                o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)(kt1 - kt0), o[7] = 0;
+            }
+            return;     // the probe build leaves C alone
+        }
     } else {
         stage(0, kt0);
         for (int kt = kt0; kt < kt1; ++kt) {
@@ -1231,9 +1364,9 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
         }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool PP = false>
+template <typename T, int BM, int BN, int WM, int WN, bool PP = false, bool PROBE = false, bool R4 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_tn_kernel(const GemmTN p) {
-    gemm_tn_body<T, BM, BN, WM, WN, PP>(p, xcd_remap(blockIdx.x, gridDim.x));
+    gemm_tn_body<T, BM, BN, WM, WN, PP, PROBE, R4>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Up to MAX_TN_PROBS weight-gradient problems in ONE launch of 256x256 tiles (the four to six linears of one or
@@ -1253,7 +1386,7 @@ struct GemmTNMulti {
     GemmTN p[MAX_TN_PROBS];
     uint16_t order[MAX_TN_ORDER];
 };
-template <typename T>
+template <typename T, bool R4 = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti mp) {
     const uint32_t code = mp.order[blockIdx.x];
     if (code == TN_NOP) return;
@@ -1272,7 +1405,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti
     p.alpha = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.alpha)));
     p.slab = nullptr;
     p.mode = __builtin_amdgcn_readfirstlane(q.mode);
-    gemm_tn_body<T, 256, 256, 2, 4, true>(p, lid_in);
+    gemm_tn_body<T, 256, 256, 2, 4, true, false, R4>(p, lid_in);
 }
 
 // C[r, c] += alpha * sum_s slab[s, r, c]   (one float4 per thread)
@@ -1656,6 +1789,17 @@ TnPlan tn_plan(int M, int N1, int N2, int splits_req, int force_tile) {
 }
 }  // namespace
 
+namespace {
+// measurement aid: VLMO_TN_RING4=0 selects the two-buffer 64-token staging of the bf16 ping-pong weight-gradient kernels
+bool tn_ring4() {
+    static const bool v = [] {
+        const char* e = getenv("VLMO_TN_RING4");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+}  // namespace
+
 extern "C" int64_t vlmo_gemm_tn_ws_bytes(int M, int N1, int N2) {
     const TnPlan a = tn_plan(M, N1, N2, 0, 0);
     return (int64_t)a.splits * N1 * N2 * 4;
@@ -1670,6 +1814,7 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     VLMO_CHECK_ARG(lda >= N1 && ldb >= N2 && ldc >= N2, "vlmo_gemm_tn: leading dimension too small");
     VLMO_CHECK_ARG(dtype == VLMO_BF16 || dtype == VLMO_F16, "vlmo_gemm_tn: dtype must be bf16 or f16");
     int force = 0;
+    const bool probe = splits >= 3000;      // diagnostic: 3000 + s = the 256x256 kernel with segment stamps -> ws (C untouched)
     if (splits >= 1000) {      // test hook: 1000 + s forces 128x128 tiles, 2000 + s forces 256x256
         force = splits >= 2000 ? 256 : 128;
         splits %= 1000;
@@ -1682,17 +1827,38 @@ extern "C" int vlmo_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     GemmTN p{A, B, C, M, N1, N2, lda, ldb, ldc, pl.per, pl.tiles, alpha, use_slab ? ws : nullptr, TN_ATOMIC};
     dim3 grid(pl.tiles * pl.splits);
     ProfScope prof(64 + (pl.big ? 8 : 0), 2.0 * M * N1 * N2, stream);
+    const bool r4 = tn_ring4();
+    if (probe) {
+        VLMO_CHECK_ARG(pl.big && ws && ws_bytes >= (int64_t)pl.tiles * pl.splits * 8 * 64 && dtype == VLMO_BF16, "vlmo_gemm_tn: probe needs the 256x256 plan, bf16 and a stamp buffer");
+        constexpr int LDS = 2 * 4 * 64 * 256;
+        static DeviceOnce pattr;
+        if (pattr.first()) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        }
+        GemmTN pp_ = p;
+        pp_.slab = ws;
+        if (r4)
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4, true, true, true>), grid, dim3(512), LDS, stream, pp_);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4, true, true, false>), grid, dim3(512), LDS, stream, pp_);
+        VLMO_CHECK_LAUNCH("vlmo_gemm_tn(probe)");
+        return 0;
+    }
     if (pl.big) {
         constexpr int LDS = 2 * 4 * 64 * 256;
         static DeviceOnce attr;
         if (attr.first()) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16, 256, 256, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16, 256, 256, 2, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16, 256, 256, 2, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         }
         if (dtype == VLMO_F16)
-            hipLaunchKernelGGL((gemm_tn_kernel<f16, 256, 256, 2, 4, true>), grid, dim3(512), LDS, stream, p);
+            hipLaunchKernelGGL((gemm_tn_kernel<f16, 256, 256, 2, 4, true, false, true>), grid, dim3(512), LDS, stream, p);
+        else if (r4)
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4, true, false, true>), grid, dim3(512), LDS, stream, p);
         else
-            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4, true>), grid, dim3(512), LDS, stream, p);
+            hipLaunchKernelGGL((gemm_tn_kernel<bf16, 256, 256, 2, 4, true, false, false>), grid, dim3(512), LDS, stream, p);
     } else {
         if (dtype == VLMO_F16)
             hipLaunchKernelGGL((gemm_tn_kernel<f16, 128, 128, 2, 2>), grid, dim3(256), 65536, stream, p);
@@ -1718,8 +1884,9 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
     static DeviceOnce attr;
     if (attr.first()) {
         constexpr int LDS = 2 * 4 * 64 * 256;
-        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
     for (int q0 = 0, nq = 0; q0 < n; q0 += nq) {
         // one launch = as many of the remaining problems as fit the problem table and the placement table
@@ -1809,9 +1976,11 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         ProfScope prof(73, flops, stream);
         constexpr int LDS = 2 * 4 * 64 * 256;
         if (dtype == VLMO_F16)
-            hipLaunchKernelGGL(gemm_tn_multi_kernel<f16>, dim3(t), dim3(512), LDS, stream, mp);
+            hipLaunchKernelGGL((gemm_tn_multi_kernel<f16, true>), dim3(t), dim3(512), LDS, stream, mp);
+        else if (tn_ring4())
+            hipLaunchKernelGGL((gemm_tn_multi_kernel<bf16, true>), dim3(t), dim3(512), LDS, stream, mp);
         else
-            hipLaunchKernelGGL(gemm_tn_multi_kernel<bf16>, dim3(t), dim3(512), LDS, stream, mp);
+            hipLaunchKernelGGL((gemm_tn_multi_kernel<bf16, false>), dim3(t), dim3(512), LDS, stream, mp);
         VLMO_CHECK_LAUNCH("vlmo_gemm_tn_multi");
     }
     return 0;
