@@ -347,6 +347,14 @@ def main():
         hs.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     host_ms = sorted(hs)[1] * 1e3
+    comm_ms_per_step = None
+    if reducer is not None:
+        # three more steps (all ranks: the exchange is collective) with event pairs on the communication stream
+        reducer.timing = True
+        for _ in range(3):
+            step()
+        comm_ms_per_step = round(reducer.comm_ms() / 3, 4)
+        reducer.timing = False
     log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue with an empty queue {host_ms:.2f} ms/step; '
         f'{t_issue / args.steps * 1e3:.2f} ms/step while the queue is full)')
     if rank == 0:
@@ -435,6 +443,10 @@ def main():
                                        'hbm_frac': round(pmc['step'].get('hbm_gbs', 0) / PEAK_HBM_GBS, 4),
                                        'mfma_busy': pmc['step'].get('mfma_busy')}
         out['host_enqueue_ms'] = round(host_ms, 3)
+        if reducer is not None:
+            # what a scaling run needs to check the exchange: communicator size as the communicator reports it, the
+            # form chosen at start-up (GradReducer.autotune), bytes per step, time of the communication stream per step
+            out['comm'] = dict(reducer.describe(), comm_stream_ms_per_step=comm_ms_per_step)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.preset)
         sys.stdout.flush()

@@ -8,6 +8,7 @@
 // fp32 -> bf16 with the 1 / world scaling folded in, and back.
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 #include "common.h"
 #include "vlmo_hip.h"
 
@@ -23,6 +24,7 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
     int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -31,29 +33,31 @@ struct Rccl {
 };
 
 Rccl* rccl() {
+    // resolved once, thread-safe: two threads making their first vlmo_comm_* call must not race on the table
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.ok ? &r : nullptr;
-    tried = true;
-    const char* names[] = {"librccl.so", "librccl.so.1"};
-    // a copy that is in the process already (PyTorch's) first, then the system's
-    for (int pass = 0; pass < 2 && !r.lib; ++pass)
-        for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
-            if (r.lib) break;
-        }
-    if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!r.lib) return nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        // a copy that is in the process already (PyTorch's) first, then the system's
+        for (int pass = 0; pass < 2 && !r.lib; ++pass)
+            for (const char* n : names) {
+                r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (r.lib) break;
+            }
+        if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) return;
 #define SYM(field, name) *(void**)(&r.field) = dlsym(r.lib, name)
-    SYM(GetUniqueId, "ncclGetUniqueId");
-    SYM(CommInitRank, "ncclCommInitRank");
-    SYM(CommDestroy, "ncclCommDestroy");
-    SYM(AllReduce, "ncclAllReduce");
-    SYM(ReduceScatter, "ncclReduceScatter");
-    SYM(AllGather, "ncclAllGather");
-    SYM(GetErrorString, "ncclGetErrorString");
+        SYM(GetUniqueId, "ncclGetUniqueId");
+        SYM(CommInitRank, "ncclCommInitRank");
+        SYM(CommDestroy, "ncclCommDestroy");
+        SYM(CommCount, "ncclCommCount");
+        SYM(AllReduce, "ncclAllReduce");
+        SYM(ReduceScatter, "ncclReduceScatter");
+        SYM(AllGather, "ncclAllGather");
+        SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.ReduceScatter && r.AllGather;
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.ReduceScatter && r.AllGather;
+    });
     return r.ok ? &r : nullptr;
 }
 
@@ -160,9 +164,25 @@ int vlmo_comm_init(void** out, const void* id, int rank, int world) {
     return 0;
 }
 
+int vlmo_comm_count(void* comm, int* ranks, int* rank) {
+    GET_COMM(c, comm, "vlmo_comm_count");
+    VLMO_CHECK_ARG(ranks, "vlmo_comm_count: null output");
+    int n = c->world;
+    if (r->CommCount) {         // what the COMMUNICATOR says, not what the caller passed to vlmo_comm_init
+        const int rc = r->CommCount(c->comm, &n);
+        if (rc != kNcclSuccess) return fail(r, "vlmo_comm_count", rc);
+    }
+    *ranks = n;
+    if (rank) *rank = c->rank;
+    return 0;
+}
+
 int vlmo_comm_destroy(void* comm) {
     if (!comm) return 0;
     GET_COMM(c, comm, "vlmo_comm_destroy");
+    // every collective enqueued through this communicator must have finished: the device is drained here, the caller
+    // does not have to remember the streams it used
+    (void)hipDeviceSynchronize();
     const int rc = r->CommDestroy(c->comm);
     c->magic = 0;
     delete c;

@@ -164,6 +164,131 @@ class GradReducer:
             engine.GRAD_SINK = self
         if broadcast_params and self.world > 1:
             self.sync_params(module)
+        # Which form of the exchange is faster depends on the node (xGMI is point to point: a ring all-reduce is per-link
+        # bound, reduce-scatter + all-gather use all links; SURVEY.md 5.8 estimates 4.6 vs 0.66 ms for VLMo-Base) and nobody
+        # could measure it on the one-GPU development boxes: with more than one rank, time the candidates on a buffer of a
+        # real bucket's size at start-up and keep the fastest.  Explicit choices (VLMO_DP_COLLECTIVE, comm=...) are kept.
+        self.tuned = None
+        if self.world > 1 and os.environ.get('VLMO_DP_AUTOTUNE', '1') != '0':
+            self.autotune(try_native=(comm is None and 'VLMO_DP_COMM' not in os.environ and self.on_gpu),
+                          try_collective='VLMO_DP_COLLECTIVE' not in os.environ)
+
+    # ------------------------------------------------------------ start-up choice of the exchange
+    def _time_exchange(self, buf, reps):
+        """seconds per in-place sum of `buf` over the ranks with the current settings (max over `reps` after 2 warm-ups is
+        not needed: the median of the timed repetitions; every rank times its own, the caller takes the max over ranks)."""
+        import time
+        ts = []
+        for i in range(reps + 2):
+            if self.on_gpu:
+                with torch.cuda.stream(self.comm_stream):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    self._c_all_reduce(buf).wait()
+                    b.record()
+                b.synchronize()
+                t = a.elapsed_time(b) * 1e-3
+            else:
+                dist.barrier(group=self.pg)
+                t0 = time.perf_counter()
+                self._c_all_reduce(buf).wait()
+                t = time.perf_counter() - t0
+            if i >= 2:
+                ts.append(t)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    def autotune(self, try_native=False, try_collective=True, numel=None, reps=5):
+        """Pick (communicator, collective form) by timing them on a buffer the size of the largest gradient bucket.  Every
+        rank measures, the per-candidate MAX over the ranks decides, so all ranks make the same choice.  Returns the
+        table of candidates -> seconds and stores it (with the choice) in self.tuned."""
+        if self.world < 2:
+            return None
+        n = numel or max(b.padded for b in self.buckets)
+        n = ((n + self.world * 8 - 1) // (self.world * 8)) * (self.world * 8)
+        buf = torch.zeros(n, dtype=self.comm_dtype, device=self.device)
+        native0 = self.native
+        made_native = None
+        if try_native and self.native is None:
+            # the library's own communicator joins the candidates; a failure to create it on ANY rank drops it everywhere
+            ok = torch.ones(1, dtype=torch.int32, device=self.device)
+            try:
+                from . import hip
+                uid = [hip.comm_unique_id() if self.rank == 0 else None]
+                src = dist.get_global_rank(self.pg, 0) if self.pg is not dist.group.WORLD else 0
+                dist.broadcast_object_list(uid, src=src, group=self.pg)
+                with torch.cuda.device(self.device):
+                    made_native = hip.comm_init(uid[0], self.rank, self.world)
+            except Exception:       # noqa: BLE001 -- any failure means "not a candidate"
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+            if int(ok.item()) == 0 and made_native is not None:
+                from . import hip
+                hip.comm_destroy(made_native)
+                made_native = None
+        comms = [('torch', None)] if native0 is None else [('native', native0)]
+        if made_native is not None:
+            comms.append(('native', made_native))
+        forms = ['all_reduce', 'rs_ag'] if (try_collective and n % self.world == 0) else ['rs_ag' if self.rs_ag else 'all_reduce']
+        cands, times = [], []
+        for cname, handle in comms:
+            for form in forms:
+                self.native, self.rs_ag = handle, form == 'rs_ag'
+                cands.append((cname, form, handle))
+                times.append(self._time_exchange(buf, reps))
+        tt = torch.tensor(times, dtype=torch.float64, device=self.device if self.on_gpu else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
+        best = int(torch.argmin(tt).item())
+        cname, form, handle = cands[best]
+        self.native, self.rs_ag, self.comm_mode = handle, form == 'rs_ag', cname
+        if made_native is not None and handle is not made_native:
+            from . import hip
+            if self.on_gpu:
+                torch.cuda.synchronize(self.device)
+            hip.comm_destroy(made_native)
+        self.tuned = {'bytes': n * buf.element_size(), 'chosen': f'{cname}/{form}',
+                      'candidates_ms': {f'{c}/{f}': round(float(t) * 1e3, 4) for (c, f, _), t in zip(cands, tt.tolist())}}
+        if self.rank == 0:
+            print(f'[GradReducer] exchange of a {self.tuned["bytes"] / 1e6:.1f} MB bucket over {self.world} ranks: '
+                  f'{self.tuned["candidates_ms"]} ms -> {self.tuned["chosen"]}', flush=True)
+        return self.tuned
+
+    # optional timing of the exchange: event pairs on the communication stream around pack -> collective -> unpack
+    timing = False
+
+    def _t0(self):
+        if self.timing and self.on_gpu:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            return e
+        return None
+
+    def _t1(self, e0):
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            self.__dict__.setdefault('_tev', []).append((e0, e1))
+
+    def comm_ms(self):
+        """milliseconds the communication stream spent in pack / collective / unpack since timing was switched on
+        (synchronises); resets the record."""
+        if self.on_gpu:
+            torch.cuda.synchronize(self.device)
+        tot = sum(a.elapsed_time(b) for a, b in self.__dict__.get('_tev', []))
+        self.__dict__['_tev'] = []
+        return tot
+
+    def describe(self):
+        """What a scaling run needs to check this reducer: the size of the communicator as the COMMUNICATOR reports it, the
+        form of the exchange, bytes on the wire per step and rank (before the ring / tree factor)."""
+        ranks = self.world
+        if self.native is not None:
+            from . import hip
+            ranks = hip.comm_count(self.native)
+        return {'ranks_in_communicator': ranks, 'communicator': self.comm_mode, 'backend': dist.get_backend(self.pg),
+                'collective': ('reduce_scatter' if self.reduce_scatter else ('rs_ag' if self.rs_ag else 'all_reduce')),
+                'comm_dtype': str(self.comm_dtype).replace('torch.', ''), 'bytes_per_step': self.bytes_per_step(),
+                'autotune': self.tuned}
 
     def close(self):
         """Detach from the engine (block gradients go back through autograd) and drop the buckets."""
@@ -398,6 +523,7 @@ class GradReducer:
         flat, comm = a.flat[lo:hi], a.comm[lo:hi]
         self._comm_wait()
         with torch.cuda.stream(self.comm_stream):
+            t0 = self._t0()
             if comm.data_ptr() != flat.data_ptr():
                 self._pack(flat, comm)
             else:
@@ -406,6 +532,7 @@ class GradReducer:
             work.wait()
             if comm.data_ptr() != flat.data_ptr():
                 self._unpack_into(comm, flat)
+            self._t1(t0)
         for sb in sbs:
             sb.work, sb.unpacked, sb.reduced, sb.has_grad = work, True, True, True
 
@@ -420,6 +547,7 @@ class GradReducer:
             from contextlib import nullcontext
             ctxm = nullcontext()
         with ctxm:
+            t0 = self._t0()
             src = sb.comm
             if sb.comm is not sb.flat:
                 self._pack(sb.flat, sb.comm)        # ONE pass: 1/world scaling + fp32 -> bf16 pack
@@ -448,6 +576,7 @@ class GradReducer:
                 # instead of running 30 times on the main stream at the end of the step
                 sb.work.wait()
                 self._unpack_sink(sb)
+                self._t1(t0)
 
     def _unpack_sink(self, sb):
         if self.reduce_scatter:
@@ -476,6 +605,7 @@ class GradReducer:
             from contextlib import nullcontext
             ctxm = nullcontext()
         with ctxm:
+            t0 = self._t0()
             # pack: grads of this pass, zeros for parameters this pass did not touch
             b.had = []
             for p, off, u in zip(b.params, b.offsets, b.used):
@@ -502,6 +632,7 @@ class GradReducer:
             if self.on_gpu:
                 b.work.wait()           # orders the communication stream after the collective (no host block)
                 self._unpack(b)
+                self._t1(t0)
         b.launched = b.has_grad = True
 
     def _unpack(self, b):

@@ -200,11 +200,18 @@ def _side_stream(dev):
     return s
 
 
+_PROBE_SCRATCH = {}
+
+
 def _queued_behind(dev, busy, cand):
     """True when work on stream `cand` waits for kernels on stream `busy` (the two share a hardware queue, or their
     queues share a command-processor pipe): a long memory-bound kernel sequence goes to `busy`, a one-element kernel
     to `cand` right behind it; sharing shows as the small kernel finishing only when the long ones have."""
-    scratch = torch.empty(1 << 26, device=dev)                 # 256 MB: one pass ~0.1 ms, far more than one dispatch round
+    # one 64 MB scratch per device, kept: a probe per rank and candidate at start-up must not allocate 256 MB each time
+    # (8 ranks x up to 16 probes); 24 passes of ~25 us keep `busy` occupied for the same ~0.6 ms
+    scratch = _PROBE_SCRATCH.get(dev)
+    if scratch is None:
+        scratch = _PROBE_SCRATCH[dev] = torch.empty(1 << 24, device=dev)
     tiny = torch.empty(64, device=dev)
     votes = 0
     for _ in range(2):
@@ -213,7 +220,7 @@ def _queued_behind(dev, busy, cand):
         with torch.cuda.stream(busy):
             scratch.zero_()                                     # the timer starts once `busy` is running
             t0.record()
-            for _ in range(6):
+            for _ in range(24):
                 scratch.mul_(1.0)
             t1.record()
         with torch.cuda.stream(cand):

@@ -57,6 +57,7 @@ class LinearCrossEntropyFn(torch.autograd.Function):
         nvalid = valid.sum().clamp(min=1).to(torch.float32)
         ctx.save_for_backward(xb, lab, lse, valid, nvalid, w, wt, b)
         ctx.dims = (n, d, V, Vp, bias is not None)
+        ctx.in_dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.mark_non_differentiable(pred)
         return rows.sum() / nvalid, pred
 
@@ -77,7 +78,10 @@ class LinearCrossEntropyFn(torch.autograd.Function):
             db = torch.zeros(Vp, dtype=torch.float32, device=dev)
             hip.colsum(dlog, db, n, Vp)
             db = db[:V]
-        return dx, dw[:V], db, None, None, None
+        # autograd wants every gradient in its input's dtype: under torch.autocast the activations that reach this head may
+        # be half precision (multimodal.py:276-279 runs the module inside autocast)
+        xd, wd, bd = ctx.in_dtypes
+        return dx.to(xd), dw[:V].to(wd), (db.to(bd) if db is not None else None), None, None, None
 
 
 class BertPredictionHeadTransform(nn.Module):

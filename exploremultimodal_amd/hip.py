@@ -126,6 +126,7 @@ _SIGS = {
     'vlmo_comm_unique_id': [_vp],
     'vlmo_comm_init': [ctypes.POINTER(ctypes.c_void_p), _vp, _i32, _i32],
     'vlmo_comm_destroy': [_vp],
+    'vlmo_comm_count': [_vp, _vp, _vp],
     'vlmo_comm_all_reduce': [_vp, _vp, _vp, _i64, _i32, _vp],
     'vlmo_comm_reduce_scatter': [_vp, _vp, _vp, _i64, _i32, _vp],
     'vlmo_comm_all_gather': [_vp, _vp, _vp, _i64, _i32, _vp],
@@ -477,6 +478,13 @@ def comm_init(uid, rank, world):
 
 def comm_destroy(comm):
     _check(lib().vlmo_comm_destroy(comm), 'vlmo_comm_destroy')
+
+
+def comm_count(comm):
+    """ranks in the communicator, as RCCL reports it."""
+    n = ctypes.c_int(0)
+    _check(lib().vlmo_comm_count(comm, ctypes.byref(n), None), 'vlmo_comm_count')
+    return n.value
 
 
 def comm_all_reduce(comm, t, stream=None):

@@ -355,14 +355,18 @@ int vlmo_stream_wait_event(hipStream_t stream, void* ev);
 /* ---- gradient exchange (replaces torch DDP / DeepSpeed ZeRO-2 over NCCL, train/pretrain/multimodal.py:61-95,
  * conf/ds_stage/l2.yaml) ----
  * RCCL over xGMI, one communicator per process, collectives enqueued on the caller's stream, sum reduction.  RCCL is
- * resolved at run time (the copy already in the process, else librccl.so); without it every entry returns -1.
+ * resolved at run time (the copy already in the process, else librccl.so); without it every entry returns -1 (an argument
+ * error, message in vlmo_last_error); RCCL's own failures come back as 1000 + ncclResult_t.
  * Bootstrap: rank 0 calls vlmo_comm_unique_id and hands the 128 bytes to the other ranks by any means (the Python host
  * uses the torch.distributed store); every rank then calls vlmo_comm_init (blocks until all ranks arrived). */
 #define VLMO_COMM_ID_BYTES 128
 int vlmo_comm_available(void);
 int vlmo_comm_unique_id(void* id128);
 int vlmo_comm_init(void** comm, const void* id128, int rank, int world);
+/* waits for the device to drain (every collective enqueued through the communicator has finished), then frees it */
 int vlmo_comm_destroy(void* comm);
+/* the size of the communicator as RCCL reports it (ncclCommCount) and this process' rank in it (rank may be NULL) */
+int vlmo_comm_count(void* comm, int* ranks, int* rank);
 int vlmo_comm_all_reduce(void* comm, const void* send, void* recv, int64_t count, int dtype, hipStream_t stream);
 /* send [world * recv_count] -> recv [recv_count] = this rank's slice of the sum (ZeRO-2 gradient partition) */
 int vlmo_comm_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype,

@@ -16,10 +16,60 @@ Follows, line by line:
   * VLMO.forward_interval         models/vlmo/vlmo.py:326-355
   * BertPooler                    tanh(W x[:,0] + b), vlmo_module.py:379
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
 LN_EPS = 1e-12
+
+# ---- bf16-operand mode (round 4): the same restatement with every matrix-product OPERAND rounded to bf16 at the points
+# where the HIP engine holds bf16 (LayerNorm outputs, qkv, soft-max probabilities, attention context, GELU output, weight
+# shadows, image patches) and fp32 everywhere else (accumulation, bias, residual stream, LayerNorm / soft-max statistics,
+# GELU argument).  What is left between the engine and THIS oracle is summation order and the rare value that sits on a
+# rounding boundary, so the comparison can be held to ~1e-3 instead of the ~3e-2 that bf16 operands cost against the fp32
+# restatement: a wrong tile or a missed term no longer hides under rounding noise.  Activation gradients are rounded at
+# the same points on the way back (the engine's dy1 / dqkv / dctx / du are bf16 GEMM operands too); parameter gradients
+# stay fp32.  The fp32 mode above remains the restatement that is pinned to the reference.
+_BF16 = [False]
+
+
+@contextlib.contextmanager
+def bf16_operands(enabled=True):
+    prev = _BF16[0]
+    _BF16[0] = bool(enabled)
+    try:
+        yield
+    finally:
+        _BF16[0] = prev
+
+
+class _RoundAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _RoundWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        return w.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _ra(x):
+    return _RoundAct.apply(x) if _BF16[0] else x
+
+
+def _rw(w):
+    return _RoundWeight.apply(w) if _BF16[0] else w
 
 
 def layer_norm(x, w, b):
@@ -35,40 +85,40 @@ def attention(sd, p, x, mask, num_heads):
         qkv_bias = torch.cat((sd[p + 'q_bias'],
                               torch.zeros_like(sd[p + 'v_bias']),
                               sd[p + 'v_bias']))
-    qkv = F.linear(x, sd[p + 'qkv.weight'], qkv_bias)
+    qkv = _ra(F.linear(x, _rw(sd[p + 'qkv.weight']), qkv_bias))
     qkv = qkv.reshape(B, N, 3, num_heads, dh).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     attn = (q @ k.transpose(-2, -1)) * dh ** -0.5
     if mask is not None:
         attn = attn.masked_fill(~mask.bool()[:, None, None, :], float('-inf'))
     attn = attn.softmax(dim=-1)
-    x = (attn @ v).transpose(1, 2).reshape(B, N, C)
-    x = F.linear(x, sd[p + 'proj.weight'], sd[p + 'proj.bias'])
+    x = _ra((_ra(attn) @ v).transpose(1, 2).reshape(B, N, C))
+    x = F.linear(x, _rw(sd[p + 'proj.weight']), sd[p + 'proj.bias'])
     return x, attn
 
 
 def mlp(sd, p, x):
-    h = F.gelu(F.linear(x, sd[p + 'fc1.weight'], sd[p + 'fc1.bias']))
-    return F.linear(h, sd[p + 'fc2.weight'], sd[p + 'fc2.bias'])
+    h = _ra(F.gelu(F.linear(x, _rw(sd[p + 'fc1.weight']), sd[p + 'fc1.bias'])))
+    return F.linear(h, _rw(sd[p + 'fc2.weight']), sd[p + 'fc2.bias'])
 
 
 def block(sd, i, x, mask, route, num_heads):
     """vlmo.py:187-197 (both branches; eval-mode DropPath = identity)."""
     p = f'blocks.{i}.'
     a, _ = attention(sd, p + 'attn.',
-                     layer_norm(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias']),
+                     _ra(layer_norm(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias'])),
                      mask, num_heads)
     has_gamma = p + 'gamma_1' in sd         # init_values=None: no layer-scale (vlmo.py:158-162, 190-192)
     x = x + (sd[p + 'gamma_1'] * a if has_gamma else a)
     m = mlp(sd, p + f'mlp.{route}.',
-            layer_norm(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias']))
+            _ra(layer_norm(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias'])))
     x = x + (sd[p + 'gamma_2'] * m if has_gamma else m)
     return x
 
 
 def embed_img(sd, mc, img, bool_masked_pos=None, img_token_type_idx=1):
     """vlmo.py:298-319 with timm PatchEmbed = conv(k=s=patch).flatten(2).T."""
-    x = F.conv2d(img, sd['patch_embed.proj.weight'], sd['patch_embed.proj.bias'],
+    x = F.conv2d(_ra(img), _rw(sd['patch_embed.proj.weight']), sd['patch_embed.proj.bias'],
                  stride=mc.patch_size)
     x = x.flatten(2).transpose(1, 2)
     B, S, _ = x.shape

@@ -532,3 +532,68 @@ def test_zero2_sharded_step_equals_replicated_step_world2_gloo():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+def _tune_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.pop('VLMO_DP_COLLECTIVE', None)
+    os.environ.pop('VLMO_DP_AUTOTUNE', None)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from exploremultimodal_amd.dp import GradReducer
+        torch.manual_seed(5)
+        model = Tiny()
+        red = GradReducer(model)
+        assert red.tuned is not None and set(red.tuned['candidates_ms']) == {'torch/all_reduce', 'torch/rs_ag'}, red.tuned
+        assert red.tuned['chosen'] in red.tuned['candidates_ms']
+        # every rank made the same choice (the per-candidate MAX over the ranks decides)
+        got = [None] * world
+        dist.all_gather_object(got, (red.tuned['chosen'], red.rs_ag, red.tuned['candidates_ms']))
+        assert all(g_ == got[0] for g_ in got), got
+        d = red.describe()
+        assert d['ranks_in_communicator'] == world and d['collective'] in ('all_reduce', 'rs_ag') and d['bytes_per_step'] > 0
+        assert d['autotune']['chosen'] == red.tuned['chosen']
+        # ... and the exchange still averages
+        g = torch.Generator().manual_seed(3 + rank)
+        x = torch.randn(5, 8, generator=g)
+        loss = model(x).square().mean()
+        red.prepare(loss)
+        loss.backward()
+        red.finish()
+        ref = Tiny()
+        ref.load_state_dict(model.state_dict())
+        ref(x).square().mean().backward()
+        for (n, p), pr in zip(model.named_parameters(), ref.parameters()):
+            if 'unused' in n:
+                continue
+            want = pr.grad.clone()
+            dist.all_reduce(want)
+            want /= world
+            assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), n
+        # an explicit choice is kept: no tuning of the collective form
+        os.environ['VLMO_DP_COLLECTIVE'] = 'rs_ag'
+        red2 = GradReducer(Tiny())
+        assert red2.rs_ag and list(red2.tuned['candidates_ms']) == ['torch/rs_ag']
+        q.put((rank, 'ok'))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc() + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_autotune_world2_gloo():
+    """With more than one rank the reducer times all-reduce against reduce-scatter + all-gather on a bucket-sized buffer at
+    start-up (the choice must not need the builder on a multi-GPU box), all ranks agree on the
+    choice, GradReducer.describe() reports what a scaling run needs, and an explicit VLMO_DP_COLLECTIVE is kept."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'

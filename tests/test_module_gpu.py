@@ -218,3 +218,44 @@ def test_objectives_with_nothing_masked_return_python_zero():
     assert torch.isfinite(ret['itc_task_loss']) and torch.isfinite(ret['itm_task_loss'])
     total = sum(v for k, v in ret.items() if 'task_loss' in k)
     total.backward()
+
+
+@pytest.mark.parametrize('fused_ce', [False, True])
+@pytest.mark.parametrize('amp_dtype', [torch.float16, torch.bfloat16])
+def test_module_under_autocast_like_the_reference_loop(golden_dir, amp_dtype, fused_ce):
+    """The reference's train step calls the model INSIDE torch.cuda.amp.autocast() and steps through its loss scaler with
+    clip 5.0 (train/pretrain/multimodal.py:276-333, utils/utils.py:343-364).  Under autocast the torch-op heads (pooler,
+    MLM transform, ITC / ITM linears) run in half precision around the engine's autograd Functions, which keep their own
+    precision plan (fp32 residual stream, bf16 GEMM operands): losses stay within the fixture tolerance of the fp32
+    reference run, every gradient is finite and has its parameter's dtype, and the scaler's step changes the weights."""
+    from exploremultimodal_amd import optim
+    g = np.load(os.path.join(golden_dir, 'module_base_b2.npz'))
+    B = int(g['meta.B'])
+    model, cfg = _build('base')
+    cfg.train.fused_ce = fused_ce
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, B, seed=1234).items()}
+    batch['itm_neg_idx'] = (torch.from_numpy(g['itm_img_neg_idx']).to(DEV), torch.from_numpy(g['itm_txt_neg_idx']).to(DEV))
+    with torch.autocast('cuda', dtype=amp_dtype):
+        ret = model(batch)
+    for ln in LOSSES:
+        got, ref = float(ret[f'{ln}_task_loss']), float(g[f'ret.{ln}_task_loss'])
+        # half-precision heads on top of the bf16 backbone: fixture tolerance x 1.5
+        assert abs(got - ref) <= 3e-2 + 3e-3 * abs(ref), (ln, got, ref)
+    total = sum(v for k, v in ret.items() if 'task_loss' in k)
+    assert total.dtype == torch.float32
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params[:8]]
+    opt = optim.FusedAdam([{'params': params, 'lr': 1e-4, 'weight_decay': 0.01}], betas=(0.9, 0.98), eps=1e-8)
+    scaler = optim.NativeScalerWithGradNormCount()
+    norm = scaler(total, opt, clip_grad=5.0, parameters=params, update_grad=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.as_tensor(norm)).all() and float(norm) > 0
+    seen = 0
+    for n_, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        seen += 1
+        assert p.grad.dtype == p.dtype, (n_, p.grad.dtype)
+        assert torch.isfinite(p.grad).all(), n_
+    assert seen > 100
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, params[:8]))

@@ -138,7 +138,7 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
     reds = []
     try:
         cfg = synth.make_config('mini', loss_names=['mlm', 'itc'])     # no sampled negatives: both runs see the same graph
-        results = []
+        results, grads = {}, {}
         for mode in ('zero2', 'replicated'):
             torch.manual_seed(0)
             model = build_model(cfg).to(DEV).train()
@@ -150,7 +150,8 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
             opt = ZeroAdam(red, groups, betas=(0.9, 0.98), eps=1e-6) if mode == 'zero2' else \
                 optim.FusedAdam(groups, betas=(0.9, 0.98), eps=1e-6)
             batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, 4, seed=3).items()}
-            inits = {n: p.detach().clone() for n, p in model.named_parameters()}
+            named = list(model.named_parameters())
+            inits = {n: p.detach().clone() for n, p in named}
             for step in range(3):
                 for p in model.parameters():
                     p.grad = None
@@ -160,29 +161,32 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
                 red.prepare(loss)
                 loss.backward()
                 red.finish()
+                torch.cuda.synchronize()
+                # Two runs of a step do not reproduce bit for bit (fp32 atomics in the weight-gradient / column-sum /
+                # embedding kernels: ~1e-6 of the terms summed), and Adam turns the sign of a near-zero gradient into a
+                # full-size update.  So the runs are compared where that noise is harmless -- the reduced GRADIENTS, element
+                # by element within 1e-4 of the tensor's largest -- and the optimizers then step on IDENTICAL gradients
+                # (the zero2 run's), which makes every parameter comparable element by element at 1e-5 of its update.
+                if mode == 'zero2':
+                    grads[step] = {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+                else:
+                    assert set(grads[step]) == {n for n, p in named if p.grad is not None}
+                    for n, p in named:
+                        if p.grad is None:
+                            continue
+                        ga, gb = grads[step][n], p.grad.detach()
+                        tol = 1e-4 * gb.abs().max().item() + 1e-12
+                        assert (ga - gb).abs().max().item() <= tol, (step, n, (ga - gb).abs().max().item(), tol)
+                        p.grad.copy_(ga)
                 opt.step(clip_grad=1.0)
             torch.cuda.synchronize()
-            results.append({n: p.detach().clone() for n, p in model.named_parameters()})
+            results[mode] = {n: p.detach().clone() for n, p in named}
             red.close()
-        n_end = n_bad = 0
-        for n in results[0]:
-            a, b, w0 = results[0][n], results[1][n], inits[n]
-            # the two runs' gradients differ by fp32 summation order (atomics in the weight-gradient / column-sum /
-            # embedding kernels) and Adam turns a near-zero gradient's noise into a full-size update of that element,
-            # so the comparison is on the UPDATE as a whole: the two runs' updates agree to 3 % of their norm
-            upd = (b - w0).norm().item()
-            tol = 3e-2 if a.numel() >= 65536 else 1e-1     # small tables: one sign flip of a near-zero gradient is percents of the norm
-            assert (a - b).norm().item() <= tol * upd + 1e-7, (n, (a - b).norm().item(), upd)
-            # 3 % of a norm would hide a handful of wrong elements, which is what a mis-cut slice leaves behind (the
-            # first / last elements of a parameter's overlap with the rank's slice stepped with a neighbour's gradient,
-            # or not stepped at all: an error of the size of the whole per-element update).  So, element by element at
-            # both ends of every parameter: within a third of the update's RMS, allowing the rare near-zero-gradient
-            # element whose Adam update flips with the summation order.
-            rms = upd / max(1.0, a.numel()) ** 0.5
-            ends = torch.cat([(a - b).flatten()[:8], (a - b).flatten()[-8:]]).abs()
-            n_end += ends.numel()
-            n_bad += int((ends > rms / 3 + 1e-9).sum())
-        assert n_bad <= 0.02 * n_end, (n_bad, n_end)
+        for n in results['zero2']:
+            a, b, w0 = results['zero2'][n], results['replicated'][n], inits[n]
+            upd = (b - w0).abs().max().item()
+            err = (a - b).abs().max().item()
+            assert err <= 1e-5 * upd + 1e-9, (n, err, upd)
     finally:
         for r in reds:
             r.close()
