@@ -707,10 +707,16 @@ template <int... Is, typename F> __device__ __forceinline__ void static_for(std:
 // under the K loop of the other -- was built and measured in round 4: 256 rows = the 256x128x32 tile of gemm_nt_kernel
 // (121 vs 122 us for fc1), 288 rows 125 us against 116 us for this kernel at 288 rows: the 256-row build fits THREE
 // workgroups per CU (168 registers), the 288-row one two.  Removed.)
-template <typename T, int TM, int EPI, int SCHED = 1>
+// H16 = tile height in 16-row units (12 .. 20): the wm == 0 waves own ceil(H16 / 2) accumulator tile rows, the wm == 1 waves
+// floor(H16 / 2) -- the two wave groups take turns on the matrix pipe, so a K-tile costs TMA + TMB MFMA segments whatever
+// the split, and the tile height moves in 16-row steps (208 rows: 243 tiles for N = 768 at M = 16 704; 272 rows: 744 tiles
+// = three rounds for N = 3 072; 304 rows: 495 tiles = two rounds for N = 2 304).  Everything from the accumulators on is
+// written once and instantiated per wave group (`body`); both copies execute the same barrier sequence.
+template <typename T, int H16, int EPI, int SCHED = 1>
 __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp) {
     typedef typename Elem<T>::v8 v8;
-    constexpr int BM = 32 * TM, WN = 4, BN = WN * 64, BK = 64, NW = 2 * WN, WROWS = 16 * TM;
+    constexpr int TMA = (H16 + 1) / 2, TMB = H16 / 2;
+    constexpr int BM = 16 * H16, WN = 4, BN = WN * 64, BK = 64, NW = 2 * WN;
     constexpr int ROWB = BK * 2, SRPI = 1024 / ROWB, CPR = ROWB / 16;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int NAI = BM / SRPI;                                  // A staging instructions per K-tile, whole workgroup
@@ -793,176 +799,183 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
             b_rs.load16(s + A_BYTES + (i * NW + wave) * 1024, b_off[i], koff);
     };
 
-    f32x4 acc[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int swz = (l15 >> 1) & 7;                 // nt_swz of the lane's row: row origins are multiples of 16
-    const int a_row_off = (wm * WROWS + l15) * ROWB;
-    const int b_row_off = A_BYTES + (wn * 64 + l15) * ROWB;
-    const int nk = p.K / BK;
+    auto body = [&](auto tm_c, auto row0_c) __attribute__((always_inline)) {
+        constexpr int TM = decltype(tm_c)::value, ROW0 = decltype(row0_c)::value;
+        f32x4 acc[TM][4];
+    #pragma unroll
+        for (int i = 0; i < TM; ++i)
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int l15 = lane & 15, g4 = lane >> 4;
+        const int swz = (l15 >> 1) & 7;                 // nt_swz of the lane's row: row origins are multiples of 16
+        const int a_row_off = (ROW0 + l15) * ROWB;
+        const int b_row_off = A_BYTES + (wn * 64 + l15) * ROWB;
+        const int nk = p.K / BK;
 
-    stage(0, 0);
-    {
-        // ping-pong schedule of gemm_nt_kernel<PP>: per K-tile  read k-half 0 | MFMAs | read k-half 1 | MFMAs,  the wm == 1
-        // waves one segment behind the wm == 0 waves; a k-half is ONE 32-deep MFMA step here
-        v8 af[TM], bf[4];
-        auto read_half = [&](const char* s_, int hf) {
-            const int coff = ((4 * hf + g4) ^ swz) << 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *(const v8*)(s_ + b_row_off + j * 16 * ROWB + coff);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const v8*)(s_ + a_row_off + i * 16 * ROWB + coff);
-        };
-        auto mfma_half = [&]() {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mfma16(af[i], bf[j], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto bar = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage(0, 0);
+        {
+            // ping-pong schedule of gemm_nt_kernel<PP>: per K-tile  read k-half 0 | MFMAs | read k-half 1 | MFMAs,  the wm == 1
+            // waves one segment behind the wm == 0 waves; a k-half is ONE 32-deep MFMA step here
+            v8 af[TM], bf[4];
+            auto read_half = [&](const char* s_, int hf) {
+                const int coff = ((4 * hf + g4) ^ swz) << 4;
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const v8*)(s_ + b_row_off + j * 16 * ROWB + coff);
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const v8*)(s_ + a_row_off + i * 16 * ROWB + coff);
+            };
+            auto mfma_half = [&]() {
+                __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mfma16(af[i], bf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            auto bar = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wm == 1) bar();
-        // diagnostic build (SCHED & 8): s_memtime at every segment boundary of one K loop, sums per segment kind and the
-        // in-kernel clock (cycles per 100 MHz tick of s_memrealtime) -> e.colpart[workgroup][wave][8] (tools/nt16_probe.py)
-        constexpr bool PROBE = (SCHED & 8) != 0;
-        constexpr int SCH = SCHED & 7;
-        uint64_t seg_sum[4] = {0, 0, 0, 0}, t_prev = 0, t_begin = 0, r_begin = 0;
-        auto stamp = [&](int k) {
+            if (wm == 1) bar();
+            // diagnostic build (SCHED & 8): s_memtime at every segment boundary of one K loop, sums per segment kind and the
+            // in-kernel clock (cycles per 100 MHz tick of s_memrealtime) -> e.colpart[workgroup][wave][8] (tools/nt16_probe.py)
+            constexpr bool PROBE = (SCHED & 8) != 0;
+            constexpr int SCH = SCHED & 7;
+            uint64_t seg_sum[4] = {0, 0, 0, 0}, t_prev = 0, t_begin = 0, r_begin = 0;
+            auto stamp = [&](int k) {
+                if constexpr (PROBE) {
+                    const uint64_t t = __builtin_amdgcn_s_memtime();
+                    seg_sum[k] += t - t_prev;
+                    t_prev = t;
+                }
+            };
             if constexpr (PROBE) {
-                const uint64_t t = __builtin_amdgcn_s_memtime();
-                seg_sum[k] += t - t_prev;
-                t_prev = t;
+                t_begin = t_prev = __builtin_amdgcn_s_memtime();
+                r_begin = __builtin_amdgcn_s_memrealtime();
             }
-        };
-        if constexpr (PROBE) {
-            t_begin = t_prev = __builtin_amdgcn_s_memtime();
-            r_begin = __builtin_amdgcn_s_memrealtime();
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* cur = smem + (kt & 1) * STAGE;
-            const bool more = kt + 1 < nk;
-            read_half(cur, 0);
-            // SCHED 1: the LDS-DMA of the next K-tile is issued in the READ segment, behind the fragment reads (the other
-            // buffer was last read two segments ago by this group, one segment ago by the other, each behind lgkmcnt(0) +
-            // barrier): the issue cost of the eight DMA instructions (~60-180 cycles each) then runs beside the partner
-            // wave's MFMA segment instead of in front of this wave's own
-            if (SCH == 1 && more) stage((kt + 1) & 1, kt + 1);
-            bar();
-            stamp(0);
-            if (SCH == 0 && more) stage((kt + 1) & 1, kt + 1);
-            mfma_half();
-            bar();
-            stamp(1);
-            read_half(cur, 1);
-            if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bar();
-            stamp(2);
-            mfma_half();
-            if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bar();
-            stamp(3);
-        }
-        if (wm == 0) bar();
-        if constexpr (PROBE) {
-            const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
-            if (p.e.colpart && lane == 0) {
-                uint64_t* o = (uint64_t*)p.e.colpart + ((size_t)blockIdx.x * NW + wave) * 8;
-                o[0] = seg_sum[0], o[1] = seg_sum[1], o[2] = seg_sum[2], o[3] = seg_sum[3];
-                o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)nk, o[7] = (uint64_t)__builtin_amdgcn_s_getreg(0xf814) /* XCC_ID */;
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* cur = smem + (kt & 1) * STAGE;
+                const bool more = kt + 1 < nk;
+                read_half(cur, 0);
+                // SCHED 1: the LDS-DMA of the next K-tile is issued in the READ segment, behind the fragment reads (the other
+                // buffer was last read two segments ago by this group, one segment ago by the other, each behind lgkmcnt(0) +
+                // barrier): the issue cost of the eight DMA instructions (~60-180 cycles each) then runs beside the partner
+                // wave's MFMA segment instead of in front of this wave's own
+                if (SCH == 1 && more) stage((kt + 1) & 1, kt + 1);
+                bar();
+                stamp(0);
+                if (SCH == 0 && more) stage((kt + 1) & 1, kt + 1);
+                mfma_half();
+                bar();
+                stamp(1);
+                read_half(cur, 1);
+                if (more && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar();
+                stamp(2);
+                mfma_half();
+                if (more && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar();
+                stamp(3);
             }
-        }
-    }
-
-    // ---- epilogue: accumulators -> wave-private LDS -> full-row segments, in passes of two 16-row tiles (one for the last
-    // tile of an odd TM); the arithmetic is gemm_nt_kernel's (epilogue4 / epilogue_ext)
-    __syncthreads();
-    constexpr int ROWF = 64, LPR = 16, RPI = 4;
-    float* ep = (float*)(smem + wave * (32 * ROWF * 4));
-    const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
-    const int gn = n0 + wn * 64 + rcol;
-    const bool col_ok = gn < p.N;
-    const int gnc = col_ok ? gn : 0;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
-    if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
-    if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
-    auto epi_pass = [&](auto nr_c, auto i0_c) __attribute__((always_inline)) {
-        constexpr int NR = decltype(nr_c)::value, I0 = decltype(i0_c)::value;
-        constexpr int NIT = NR * 16 / RPI;
-        const int gmb = __builtin_amdgcn_readfirstlane(m0 + wm * WROWS + I0 * 16);
-        const int gmbc = min(gmb, p.M - 1);
-        f32x4 ext[NIT];
-        float rs[NIT];
-        int ridx[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int gmc = gmbc + min(it * RPI + rrow, p.M - 1 - gmbc);
-            ridx[it] = (EPI == EPI_RESID && p.e.row_scale && p.e.row_index) ? p.e.row_index[gmc] : gmc;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
-            ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
-            rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
-        }
-        // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register
-#pragma unroll
-        for (int ii = 0; ii < NR; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(ii * 16 + 4 * g4 + r) * ROWF + j * 16 + l15] = acc[I0 + ii][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        f32x4 v[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) v[it] = *(const f32x4*)(ep + (it * RPI + rrow) * ROWF + rcol);
-        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int row = it * RPI + rrow;
-            const bool ok = gmb + row < p.M && col_ok;
-            const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
-            if constexpr (EPI == EPI_DGELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) csum[j] += ok ? w[j] : 0.f;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if constexpr (EPI == EPI_DGELU) {
-            // column sums of this pass -> colpart row of its FIRST 16-row block, zeros to the second one's (every row of
-            // colpart[ceil(M/16)] has exactly one writer, whatever the tile height)
-            if (p.e.colpart) {
-#pragma unroll
-                for (int o = LPR; o < 64; o <<= 1)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o, 64);
-                const int blk = gmb >> 4;
-                if (lane < LPR && col_ok && gmb < p.M) {
-                    *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
-                    if (NR == 2 && gmb + 16 < p.M) *(f32x4*)(p.e.colpart + (size_t)(blk + 1) * p.N + gn) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wm == 0) bar();
+            if constexpr (PROBE) {
+                const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+                if (p.e.colpart && lane == 0) {
+                    uint64_t* o = (uint64_t*)p.e.colpart + ((size_t)blockIdx.x * NW + wave) * 8;
+                    o[0] = seg_sum[0], o[1] = seg_sum[1], o[2] = seg_sum[2], o[3] = seg_sum[3];
+                    o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)nk, o[7] = (uint64_t)__builtin_amdgcn_s_getreg(0xf814) /* XCC_ID */;
                 }
             }
         }
+
+        // ---- epilogue: accumulators -> wave-private LDS -> full-row segments, in passes of two 16-row tiles (one for the last
+        // tile of an odd TM); the arithmetic is gemm_nt_kernel's (epilogue4 / epilogue_ext)
+        __syncthreads();
+        constexpr int ROWF = 64, LPR = 16, RPI = 4;
+        float* ep = (float*)(smem + wave * (32 * ROWF * 4));
+        const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+        const int gn = n0 + wn * 64 + rcol;
+        const bool col_ok = gn < p.N;
+        const int gnc = col_ok ? gn : 0;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
+        if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
+        if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
+        auto epi_pass = [&](auto nr_c, auto i0_c) __attribute__((always_inline)) {
+            constexpr int NR = decltype(nr_c)::value, I0 = decltype(i0_c)::value;
+            constexpr int NIT = NR * 16 / RPI;
+            const int gmb = __builtin_amdgcn_readfirstlane(m0 + ROW0 + I0 * 16);
+            const int gmbc = min(gmb, p.M - 1);
+            f32x4 ext[NIT];
+            float rs[NIT];
+            int ridx[NIT];
+    #pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int gmc = gmbc + min(it * RPI + rrow, p.M - 1 - gmbc);
+                ridx[it] = (EPI == EPI_RESID && p.e.row_scale && p.e.row_index) ? p.e.row_index[gmc] : gmc;
+            }
+    #pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
+                ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
+                rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
+            }
+            // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register
+    #pragma unroll
+            for (int ii = 0; ii < NR; ++ii)
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) ep[(ii * 16 + 4 * g4 + r) * ROWF + j * 16 + l15] = acc[I0 + ii][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x4 v[NIT];
+    #pragma unroll
+            for (int it = 0; it < NIT; ++it) v[it] = *(const f32x4*)(ep + (it * RPI + rrow) * ROWF + rcol);
+            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = it * RPI + rrow;
+                const bool ok = gmb + row < p.M && col_ok;
+                const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
+                if constexpr (EPI == EPI_DGELU) {
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) csum[j] += ok ? w[j] : 0.f;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (EPI == EPI_DGELU) {
+                // column sums of this pass -> colpart row of its FIRST 16-row block, zeros to the second one's (every row of
+                // colpart[ceil(M/16)] has exactly one writer, whatever the tile height)
+                if (p.e.colpart) {
+    #pragma unroll
+                    for (int o = LPR; o < 64; o <<= 1)
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o, 64);
+                    const int blk = gmb >> 4;
+                    if (lane < LPR && col_ok && gmb < p.M) {
+                        *(f32x4*)(p.e.colpart + (size_t)blk * p.N + gn) = csum;
+                        if (NR == 2 && gmb + 16 < p.M) *(f32x4*)(p.e.colpart + (size_t)(blk + 1) * p.N + gn) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        };
+        static_for(std::make_integer_sequence<int, TM / 2>{}, [&](auto pi) __attribute__((always_inline)) {
+            epi_pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * decltype(pi)::value>{});
+        });
+        if constexpr (TM & 1) epi_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, TM - 1>{});
     };
-    static_for(std::make_integer_sequence<int, TM / 2>{}, [&](auto pi) __attribute__((always_inline)) {
-        epi_pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * decltype(pi)::value>{});
-    });
-    if constexpr (TM & 1) epi_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, TM - 1>{});
+    if (wm == 0)
+        body(std::integral_constant<int, TMA>{}, std::integral_constant<int, 0>{});
+    else
+        body(std::integral_constant<int, TMB>{}, std::integral_constant<int, 16 * TMA>{});
 }
 
 // ------------------------------------------------------------------ wgrad ---
@@ -1477,10 +1490,10 @@ int launch_nt(int epi, GemmNTGroups& p, hipStream_t st) {
     return 0;
 }
 
-// 16x16x32 kernels: (32 * TM) x 256 tiles, one workgroup per CU
-template <typename T, int TM, int SCHED = 1, unsigned EMASK = 0xFu>
+// 16x16x32 kernels: (16 * H16) x 256 tiles, one workgroup per CU
+template <typename T, int H16, int SCHED = 1, unsigned EMASK = 0xFu>
 int launch_nt16(int epi, GemmNTGroups& p, hipStream_t st) {
-    constexpr int BM = 32 * TM, BN = 256, BK = 64;
+    constexpr int BM = 16 * H16, BN = 256, BK = 64;
     int tiles = 0;
     for (int q = 0; q < p.ngroups; ++q) {
         p.t0[q] = tiles;
@@ -1495,7 +1508,7 @@ int launch_nt16(int epi, GemmNTGroups& p, hipStream_t st) {
     if constexpr (((EMASK >> E) & 1u) == 0) {                                                   \
         known = false;                                                                          \
     } else {                                                                                    \
-        auto k = gemm_nt16_kernel<T, TM, E, SCHED>;                                   \
+        auto k = gemm_nt16_kernel<T, H16, E, SCHED>;                                   \
         static DeviceOnce attr_set;                                                             \
         if (LDS > 65536 && attr_set.first())                                                    \
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
@@ -1643,7 +1656,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             if (e192 * 10 <= e256 * 9) tile = 8;
         }
     }
-    // 16x16x32 tiles of (32 * TM) x 256, TM = 6 .. 10: the height is chosen so that the tiles fill whole dispatch rounds of
+    // 16x16x32 tiles of (16 * H16) x 256, H16 = 12 .. 20: the height is chosen so that the tiles fill whole dispatch rounds of
     // the 256 CUs.  Cost model (tools/nt16_bench.py, M = 16 704: the measured times of one shape are proportional to it
     // within 4 %): a launch costs rounds x tile height, rounds = ceil(tiles / 256).  The tiles picked above cost, in the same
     // units (height 8 = 256 rows): 256x256 rounds x 8, 192x256 rounds x 6, 256x128x32 (two per CU, the epilogue of one under
@@ -1664,30 +1677,35 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         else cur = (double)((count(128, 128) + 511) / 512) * 4;
         int best = 0;
         double bc = 1e30;
-        for (int tm = 6; tm <= 10; ++tm) {
-            const double c = (double)((count(32 * tm, 256) + 255) / 256) * tm;
-            if (c < bc) bc = c, best = tm;
+        for (int h16 = 12; h16 <= 20; ++h16) {
+            const double c = (double)((count(16 * h16, 256) + 255) / 256) * h16 * 0.5;
+            if (c < bc) bc = c, best = h16;
         }
-        if (bc <= cur * 0.97) tile = 100 + best;
+        if (bc <= cur * 0.97) tile = 300 + best;
     }
-    if (tile >= 106 && tile <= 110) {
-        // 16x16x32 MFMA, (32 * (tile - 100)) x 256 tile: bf16, plain GEMM (no convolution, no second segment)
-        VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 are bf16, single-source");
+    if (tile >= 106 && tile <= 110) tile = 300 + 2 * (tile - 100);      // (32 * (tile - 100)) rows = an even H16
+    if (tile >= 312 && tile <= 320) {
+        // 16x16x32 MFMA, (16 * (tile - 300)) x 256 tile: bf16, plain GEMM (no convolution, no second segment)
+        VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 / 312..320 are bf16, single-source");
         ProfScope prof(epi + 16, 2.0 * Mtot * N * K, stream);
         switch (tile) {
-            case 106: return launch_nt16<bf16, 6>(epi, gp, stream);
-            case 107: return launch_nt16<bf16, 7>(epi, gp, stream);
-            case 108: return launch_nt16<bf16, 8>(epi, gp, stream);
-            case 109: return launch_nt16<bf16, 9>(epi, gp, stream);
-            default: return launch_nt16<bf16, 10>(epi, gp, stream);
+            case 312: return launch_nt16<bf16, 12>(epi, gp, stream);
+            case 313: return launch_nt16<bf16, 13>(epi, gp, stream);
+            case 314: return launch_nt16<bf16, 14>(epi, gp, stream);
+            case 315: return launch_nt16<bf16, 15>(epi, gp, stream);
+            case 316: return launch_nt16<bf16, 16>(epi, gp, stream);
+            case 317: return launch_nt16<bf16, 17>(epi, gp, stream);
+            case 318: return launch_nt16<bf16, 18>(epi, gp, stream);
+            case 319: return launch_nt16<bf16, 19>(epi, gp, stream);
+            default: return launch_nt16<bf16, 20>(epi, gp, stream);
         }
     }
     if (tile >= 908 && tile <= 909) {       // diagnostic: segment stamps of the 256-row kernel, schedule 0 / 1 (e.colpart = stamp buffer)
         VLMO_CHECK_ARG(epi == EPI_BIAS, "vlmo_gemm_nt: the probe build has the bias epilogue only");
-        return tile == 908 ? launch_nt16<bf16, 8, 8, 1u>(epi, gp, stream) : launch_nt16<bf16, 8, 9, 1u>(epi, gp, stream);
+        return tile == 908 ? launch_nt16<bf16, 16, 8, 1u>(epi, gp, stream) : launch_nt16<bf16, 16, 9, 1u>(epi, gp, stream);
     }
-    if (tile == 208) return launch_nt16<bf16, 8, 0, 1u>(epi, gp, stream);     // measurement aid: schedule 0 (DMA issued in the MFMA segment), bias epilogue
-    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4, 8 or 106..110 (got %d)", tile);
+    if (tile == 208) return launch_nt16<bf16, 16, 0, 1u>(epi, gp, stream);     // measurement aid: schedule 0 (DMA issued in the MFMA segment), bias epilogue
+    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4, 8, 106..110 or 312..320 (got %d)", tile);
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
     if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU))) tile = 3;
     ProfScope prof(epi + (tile == 3 || tile == 8 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);

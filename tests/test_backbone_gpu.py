@@ -359,21 +359,39 @@ def test_full_batch_against_oracle(preset, B, out_tol, mean_tol, grad_tol):
         worst = max(worst, (rel, k))
         assert rel <= grad_tol, (k, rel)
     print(f'{preset} B={B}: ' + 'max err %.4f mean %.5f worst grad %.4f (%s)' % (err.max().item(), err.mean().item(), *worst))
-    # ---- the sharper instrument: the SAME restatement with its matrix-product operands rounded to bf16 where the engine
-    # holds bf16 (oracle.vlmo_oracle.bf16_operands).  What separates the two is summation order and values on a rounding
-    # boundary, so EVERY output element is held to `sharp_out` (an order of magnitude under the fp32 comparison's bound)
-    # and every parameter gradient to `sharp_grad` of its norm: a wrong tile, a missed term or a mis-keyed mask cannot
-    # hide under bf16 rounding noise here.
+    # ---- the sharper instrument.  Element-wise bounds cannot be pulled in: bf16 rounding is CHAOTIC across layers (a 1e-7
+    # summation-order difference in front of a rounding flips 1e-7 / ulp of the elements by a whole ulp, three roundings later
+    # the two computations round independently), so even the restatement with ITS operands rounded to bf16 at the engine's
+    # rounding points (oracle.vlmo_oracle.bf16_operands) stays ~2e-3 rms from the engine (measured round 4: mean |err| 0.0018
+    # against 0.0025 for the fp32 restatement, same maximum).  What that oracle does remove is the SYSTEMATIC part of the
+    # rounding (weights and activations rounded the same way on both sides), so the error against it must be pure noise:
+    # zero mean overall and per output column, no token row that stands out, unit regression slope.  12.8 M elements make
+    # these averages sharp to 1e-5 .. 1e-4 -- two orders under the element bound: a mis-added bias, a wrong scale, a
+    # mis-keyed mask or a dropped tile row shows here long before it moves the maximum.
     sd2 = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
     with vlmo_oracle.bf16_operands():
         ref2, _ = vlmo_oracle.forward_features(sd2, mc, img=batch['image'], txt=batch['text_ids'], img_attn_masks=im,
                                                txt_attn_masks=batch['text_mask'])
         (ref2 * R).sum().backward()
-    err2 = (x.detach().cpu() - ref2.detach()).abs()
-    sharp_out, sharp_mean, sharp_grad = (6e-3, 4e-4, 1.5e-2) if preset == 'base' else (9e-3, 6e-4, 2.5e-2)
-    print(f'{preset} B={B} vs bf16-operand oracle: max err %.5f mean %.6f' % (err2.max().item(), err2.mean().item()))
-    assert (err2 <= sharp_out + 2e-3 * ref2.detach().abs()).all(), err2.max().item()
-    assert err2.mean().item() <= sharp_mean, err2.mean().item()
+    r2 = ref2.detach()
+    e2 = x.detach().cpu() - r2                                   # signed
+    valid = mref.bool().unsqueeze(-1) if mref is not None else torch.ones_like(e2[..., :1], dtype=torch.bool)
+    e2v = e2[valid.expand_as(e2)].view(-1, e2.shape[-1])           # rows of real (unpadded) tokens
+    r2v = r2[valid.expand_as(r2)].view(-1, r2.shape[-1])
+    rms = e2v.square().mean().sqrt().item()
+    gmean = e2v.mean().item()
+    col = e2v.mean(0).abs().max().item()
+    row_rms = e2v.square().mean(1).sqrt()
+    slope = ((x.detach().cpu()[valid.expand_as(e2)].view(-1, e2.shape[-1]) * r2v).sum() / r2v.square().sum()).item() - 1.0
+    print(f'{preset} B={B} vs bf16-operand oracle: max |err| %.5f mean |err| %.6f rms %.6f | global mean %.2e  worst column mean %.2e  '
+          f'worst row rms / rms %.2f  slope - 1 %.2e' % (e2.abs().max().item(), e2.abs().mean().item(), rms, gmean, col,
+                                                         (row_rms.max() / rms).item(), slope))
+    depth_f = 1.0 if preset == 'base' else 1.5
+    assert rms <= 3.5e-3 * depth_f, rms
+    assert abs(gmean) <= 5e-6 * depth_f, gmean           # measured round 4: 4e-8 (Base), 3e-8 (Large)
+    assert col <= 3e-4 * depth_f, col                    # 7e-5, 1.9e-4
+    assert (row_rms.max() / rms).item() <= 5.0, (row_rms.max() / rms).item()     # 2.7, 2.3
+    assert abs(slope) <= 5e-5 * depth_f, slope           # 3e-6, 6e-6
     worst2 = (0.0, '')
     for k, p in model.named_parameters():
         gr = sd2[k].grad
@@ -382,7 +400,7 @@ def test_full_batch_against_oracle(preset, B, out_tol, mean_tol, grad_tol):
         rel = (p.grad.detach().cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
         worst2 = max(worst2, (rel, k))
     print('worst grad vs bf16-operand oracle %.4f (%s)' % worst2)
-    assert worst2[0] <= sharp_grad, worst2
+    assert worst2[0] <= (1.5e-2 if preset == 'base' else 2e-2), worst2      # 0.8 %, 1.1 %
 
 
 def test_second_backward_accumulates_in_place():

@@ -20,14 +20,14 @@ args = ap.parse_args()
 dev, M = 'cuda', args.M
 
 SHAPES = {                      # name: (epilogue, N, K, candidate tiles)
-    'fc1': (hip.EPI_BIAS_GELU, 3072, 768, [4, 3, 108, 109, 110]),
-    'qkv': (hip.EPI_BIAS, 2304, 768, [4, 3, 108, 109, 110]),
-    'dgrad_fc2': (hip.EPI_DGELU, 3072, 768, [0, 3, 108, 109, 110]),
-    'fc2': (hip.EPI_RESID, 768, 3072, [3, 8, 106, 107, 108]),
-    'proj': (hip.EPI_RESID, 768, 768, [3, 106, 107, 108]),
-    'dgrad_fc1': (hip.EPI_BIAS, 768, 3072, [3, 8, 106, 107, 108]),
-    'dgrad_qkv': (hip.EPI_BIAS, 768, 2304, [3, 106, 107, 108]),
-    'dgrad_proj': (hip.EPI_BIAS, 768, 768, [3, 106, 107, 108]),
+    'fc1': (hip.EPI_BIAS_GELU, 3072, 768, [318, 317, 4]),
+    'qkv': (hip.EPI_BIAS, 2304, 768, [320, 319, 4]),
+    'dgrad_fc2': (hip.EPI_DGELU, 3072, 768, [318, 317, 0]),
+    'fc2': (hip.EPI_RESID, 768, 3072, [314, 313, 3]),
+    'proj': (hip.EPI_RESID, 768, 768, [314, 313, 3]),
+    'dgrad_fc1': (hip.EPI_BIAS, 768, 3072, [314, 313, 3]),
+    'dgrad_qkv': (hip.EPI_BIAS, 768, 2304, [314, 313, 3]),
+    'dgrad_proj': (hip.EPI_BIAS, 768, 768, [314, 313, 3]),
 }
 names = [n for n in args.shapes.split(',') if n] or list(SHAPES)
 drop = hip.drop_params(args.drop, True)
