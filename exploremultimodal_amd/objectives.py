@@ -55,20 +55,29 @@ def compute_accuracy(logits, target):
 
 
 def _vocab_head_loss(model, head, feats, labels, vocab):
-    """Loss / logits / accuracy of a vocabulary head on gathered rows.  ``config.train.fused_ce`` or
-    ``config.train.return_logits = False``: HIP path without logits in HBM (heads.LinearCrossEntropyFn; `*_logits` is
-    then None); else the logits are returned as the reference does (objectives.py:57-68, 571-582).  With no rows the loss is the python float 0."""
+    """Loss / logits / accuracy of a vocabulary head on gathered rows (objectives.py:57-68, 571-582).
+
+    ``config.train.fused_ce``: unset (default) or True = the loss and its gradient go through the HIP path that keeps the
+    [rows, vocabulary] logits out of HBM (heads.LinearCrossEntropyFn) whenever the features live on the GPU; False = the
+    reference's ``F.cross_entropy(head(feats))``.  ``config.train.return_logits`` (default True: the reference's output
+    dict carries `mlm_logits` / `mim_logits`, objectives.py:70-77, 584-590): with the HIP loss the logits for the dict are
+    computed on the side WITHOUT a graph (nothing in the reference's loop differentiates them; a caller that does sets
+    ``fused_ce = False``); False, or ``fused_ce = True`` without an explicit ``return_logits``, returns None for them.
+    With no rows the loss is the python float 0."""
     n = labels.numel()
     tr = model.config.train
-    # the HIP path runs whenever the caller does not need the logits back: `fused_ce` asks for it outright,
-    # `return_logits = False` says the [rows, vocabulary] outputs of the reference contract are not wanted
-    # (default True: the reference's output dict, models/vlmo/objectives.py:70-77,584-590)
-    fused = bool(getattr(tr, 'fused_ce', False)) or not bool(getattr(tr, 'return_logits', True))
+    fc, rl = getattr(tr, 'fused_ce', None), getattr(tr, 'return_logits', None)
+    fused = (fc is None or bool(fc)) and feats.is_cuda
+    want_logits = (not fused) or (bool(rl) if rl is not None else fc is None)
     if n == 0:
-        return 0., (None if fused else head(feats)), torch.tensor(0, device=labels.device), 0
+        return 0., (head(feats) if want_logits else None), torch.tensor(0, device=labels.device), 0
     if fused:
         loss, pred = head.loss_and_pred(feats, labels)
-        return loss, None, (pred.to(labels.dtype) == labels).float().mean(), n
+        logits = None
+        if want_logits:
+            with torch.no_grad():
+                logits = head(feats)
+        return loss, logits, (pred.to(labels.dtype) == labels).float().mean(), n
     logits = head(feats)
     acc, cnt = compute_accuracy(logits, labels)
     return F.cross_entropy(logits.view(-1, vocab), labels.view(-1), ignore_index=-100), logits, acc, cnt

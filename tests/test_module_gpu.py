@@ -46,7 +46,7 @@ def test_build_model_contract():
         m.infer({}, infer_mode='bogus')
 
 
-@pytest.mark.parametrize('fused_ce', [False, True])
+@pytest.mark.parametrize('fused_ce', [False, True, None])
 @pytest.mark.parametrize('name,preset', [('module_mini', 'mini'), ('module_base_b2', 'base'), ('module_large_b2', 'large')])
 def test_module_forward_matches_reference(golden_dir, name, preset, fused_ce):
     """module_base_b2: the full objective at the VLMo-Base shape (BASELINE.json configs[4]'s compute_mim + in-loop
@@ -54,14 +54,21 @@ def test_module_forward_matches_reference(golden_dir, name, preset, fused_ce):
     full-vocabulary logits are pinned by every 61st column, the row log-sum-exp and the arg-max.  module_large_b2: the
     same at VLMo-Large (configs[4]'s model).  fused_ce: the two vocabulary heads through the HIP cross-entropy path
     (heads.LinearCrossEntropyFn: no logits in HBM) -- losses, accuracies and every parameter gradient against the
-    same reference fixture; the logits keys are then present with value None (documented deviation)."""
+    same reference fixture; the logits keys are then present with value None (documented deviation).  fused_ce None = the
+    DEFAULT configuration: the HIP loss path with the logits of the reference's output dict computed beside it (no graph)."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     B = int(g['meta.B'])
     model, cfg = _build(preset)
-    cfg.train.fused_ce = fused_ce
+    if fused_ce is None:
+        assert getattr(cfg.train, 'fused_ce', None) is None        # what build_model(cfg) gives without any option
+    else:
+        cfg.train.fused_ce = fused_ce
     batch = {k: v.to(DEV) for k, v in synth.synth_batch(cfg.model, B, seed=1234).items()}
     batch['itm_neg_idx'] = (torch.from_numpy(g['itm_img_neg_idx']).to(DEV), torch.from_numpy(g['itm_txt_neg_idx']).to(DEV))
     ret = model(batch)
+    if fused_ce is None:
+        assert ret['mlm_logits'] is not None and not ret['mlm_logits'].requires_grad      # logits on the side, loss through HIP
+        assert ret['mlm_task_loss'].grad_fn is not None and 'LinearCrossEntropyFn' in type(ret['mlm_task_loss'].grad_fn).__name__
     for k in g.files:
         if k.startswith('ret.'):
             kk = k[4:]
