@@ -198,7 +198,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (pairs)')
     ap.add_argument('--preset', default='base')
     ap.add_argument('--tile', type=int, default=None)
-    ap.add_argument('--comm-dtype', choices=['bf16', 'fp32'], default='bf16', help='gradient all-reduce dtype (bf16 packs/unpacks)')
+    ap.add_argument('--comm-dtype', choices=['auto', 'bf16', 'fp32'], default='auto',
+                    help='gradient exchange dtype: bf16 packs / unpacks every bucket, fp32 exchanges it in place, auto = timed at start-up')
     ap.add_argument('--merge-passes', action='store_true',
                     help='full objective only: batch the backbone passes by mode (V / L / VL): 3 passes instead of 7')
     ap.add_argument('--optimizer', action='store_true',
@@ -260,7 +261,8 @@ def main():
     if dist is not None:
         from exploremultimodal_amd.dp import GradReducer
         reducer = GradReducer(model, dist.group.WORLD, reduce_scatter=args.zero2,
-                              comm_dtype=torch.bfloat16 if (args.comm_dtype == 'bf16' and not args.rehearse_gloo) else torch.float32)
+                              comm_dtype=(torch.float32 if (args.comm_dtype == 'fp32' or args.rehearse_gloo) else
+                                          (torch.bfloat16 if args.comm_dtype == 'bf16' else None)))
 
     B = args.batch
     batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=args.objective == 'full')

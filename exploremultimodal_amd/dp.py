@@ -100,12 +100,18 @@ class _Enqueued:
 
 
 class GradReducer:
-    def __init__(self, module, process_group=None, comm_dtype=torch.bfloat16, reduce_scatter=False,
+    def __init__(self, module, process_group=None, comm_dtype=None, reduce_scatter=False,
                  broadcast_params=True, engine_sink=True, comm=None):
         """comm: 'torch' (collectives through torch.distributed, backend nccl = RCCL) or 'native' (the library's own RCCL
         communicator, include/vlmo_hip.h vlmo_comm_*: the collectives are plain enqueues on the communication stream);
-        default from VLMO_DP_COMM, else 'torch'."""
+        default from VLMO_DP_COMM, else 'torch'.
+        comm_dtype: torch.bfloat16 (half the bytes per link, one pack and one unpack pass over every bucket), torch.float32
+        (the buckets are exchanged in place), or None = decided at start-up: timed with the other candidates when there is
+        more than one rank (autotune), fp32 at world size 1 (nothing crosses a link, the two passes would be pure cost)."""
         import os
+        self._auto_dtype = comm_dtype is None
+        if comm_dtype is None:
+            comm_dtype = torch.bfloat16
         self.rs_ag = os.environ.get('VLMO_DP_COLLECTIVE', 'all_reduce') == 'rs_ag'
         self.comm_mode = comm or os.environ.get('VLMO_DP_COMM', 'torch')
         if self.comm_mode not in ('torch', 'native'):
@@ -171,10 +177,22 @@ class GradReducer:
         self.tuned = None
         if self.world > 1 and os.environ.get('VLMO_DP_AUTOTUNE', '1') != '0':
             self.autotune(try_native=(comm is None and 'VLMO_DP_COMM' not in os.environ and self.on_gpu),
-                          try_collective='VLMO_DP_COLLECTIVE' not in os.environ)
+                          try_collective='VLMO_DP_COLLECTIVE' not in os.environ,
+                          try_dtype=self._auto_dtype and self.on_gpu)
+        elif self._auto_dtype and self.world == 1:
+            self._set_comm_dtype(torch.float32)
 
     # ------------------------------------------------------------ start-up choice of the exchange
-    def _time_exchange(self, buf, reps):
+    def _set_comm_dtype(self, dtype):
+        """Switch the exchange dtype before any sink bucket exists (the hook buckets' wire buffers are re-made)."""
+        if dtype == self.comm_dtype:
+            return
+        assert not self.sinks and not self.arenas, 'the exchange dtype is fixed once gradients have been accumulated'
+        self.comm_dtype = dtype
+        for b in self.buckets:
+            b.comm = b.flat if dtype == torch.float32 else torch.zeros(b.padded, dtype=dtype, device=self.device)
+
+    def _time_exchange(self, buf, reps, wire=None):
         """seconds per in-place sum of `buf` over the ranks with the current settings (max over `reps` after 2 warm-ups is
         not needed: the median of the timed repetitions; every rank times its own, the caller takes the max over ranks)."""
         import time
@@ -184,21 +202,27 @@ class GradReducer:
                 with torch.cuda.stream(self.comm_stream):
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
-                    self._c_all_reduce(buf).wait()
+                    if wire is not None:            # fp32 bucket through a narrower wire buffer: pack -> sum -> unpack
+                        self._pack(buf, wire)
+                        self._c_all_reduce(wire).wait()
+                        self._unpack_into(wire, buf)
+                    else:
+                        buf.mul_(1.0 / self.world)
+                        self._c_all_reduce(buf).wait()
                     b.record()
                 b.synchronize()
                 t = a.elapsed_time(b) * 1e-3
             else:
                 dist.barrier(group=self.pg)
                 t0 = time.perf_counter()
-                self._c_all_reduce(buf).wait()
+                self._c_all_reduce(buf if wire is None else wire).wait()
                 t = time.perf_counter() - t0
             if i >= 2:
                 ts.append(t)
         ts.sort()
         return ts[len(ts) // 2]
 
-    def autotune(self, try_native=False, try_collective=True, numel=None, reps=5):
+    def autotune(self, try_native=False, try_collective=True, try_dtype=False, numel=None, reps=5):
         """Pick (communicator, collective form) by timing them on a buffer the size of the largest gradient bucket.  Every
         rank measures, the per-candidate MAX over the ranks decides, so all ranks make the same choice.  Returns the
         table of candidates -> seconds and stores it (with the choice) in self.tuned."""
@@ -206,7 +230,9 @@ class GradReducer:
             return None
         n = numel or max(b.padded for b in self.buckets)
         n = ((n + self.world * 8 - 1) // (self.world * 8)) * (self.world * 8)
-        buf = torch.zeros(n, dtype=self.comm_dtype, device=self.device)
+        buf = torch.zeros(n, dtype=torch.float32 if self.on_gpu else self.comm_dtype, device=self.device)
+        dtypes = [torch.bfloat16, torch.float32] if try_dtype else [self.comm_dtype]
+        wires = {d: (None if d == buf.dtype else torch.zeros(n, dtype=d, device=self.device)) for d in dtypes}
         native0 = self.native
         made_native = None
         if try_native and self.native is None:
@@ -233,23 +259,26 @@ class GradReducer:
         cands, times = [], []
         for cname, handle in comms:
             for form in forms:
-                self.native, self.rs_ag = handle, form == 'rs_ag'
-                cands.append((cname, form, handle))
-                times.append(self._time_exchange(buf, reps))
+                for d in dtypes:
+                    self.native, self.rs_ag = handle, form == 'rs_ag'
+                    cands.append((cname, form, handle, d))
+                    times.append(self._time_exchange(buf, reps, wires[d]))
         tt = torch.tensor(times, dtype=torch.float64, device=self.device if self.on_gpu else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
         best = int(torch.argmin(tt).item())
-        cname, form, handle = cands[best]
+        cname, form, handle, dsel = cands[best]
         self.native, self.rs_ag, self.comm_mode = handle, form == 'rs_ag', cname
+        self._set_comm_dtype(dsel)
         if made_native is not None and handle is not made_native:
             from . import hip
             if self.on_gpu:
                 torch.cuda.synchronize(self.device)
             hip.comm_destroy(made_native)
-        self.tuned = {'bytes': n * buf.element_size(), 'chosen': f'{cname}/{form}',
-                      'candidates_ms': {f'{c}/{f}': round(float(t) * 1e3, 4) for (c, f, _), t in zip(cands, tt.tolist())}}
+        name = lambda c, f, d: f'{c}/{f}' + (('/' + str(d).replace('torch.', '')) if len(dtypes) > 1 else '')
+        self.tuned = {'elements': n, 'chosen': name(cname, form, dsel),
+                      'candidates_ms': {name(c, f, d): round(float(t) * 1e3, 4) for (c, f, _, d), t in zip(cands, tt.tolist())}}
         if self.rank == 0:
-            print(f'[GradReducer] exchange of a {self.tuned["bytes"] / 1e6:.1f} MB bucket over {self.world} ranks: '
+            print(f'[GradReducer] exchange of a {n / 1e6:.1f} M-element gradient bucket over {self.world} ranks: '
                   f'{self.tuned["candidates_ms"]} ms -> {self.tuned["chosen"]}', flush=True)
         return self.tuned
 
@@ -526,7 +555,7 @@ class GradReducer:
             t0 = self._t0()
             if comm.data_ptr() != flat.data_ptr():
                 self._pack(flat, comm)
-            else:
+            elif self.world > 1:
                 flat.mul_(1.0 / self.world)
             work = self._c_all_reduce(comm)
             work.wait()
@@ -558,7 +587,7 @@ class GradReducer:
                 if getattr(sb, 'rs_pack', None) is None:
                     sb.rs_pack = torch.empty_like(sb.flat)
                 src = torch.mul(sb.flat, 1.0 / self.world, out=sb.rs_pack)
-            else:
+            elif self.world > 1:
                 sb.flat.mul_(1.0 / self.world)
             if self.reduce_scatter:
                 # persistent buffers: the ZeRO-2 optimizer (zero.ZeroAdam) keeps device tables of their addresses
