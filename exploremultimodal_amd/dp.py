@@ -307,6 +307,17 @@ class GradReducer:
         self.__dict__['_tev'] = []
         return tot
 
+    def agree_finite(self, *losses):
+        """True when every given loss is finite on EVERY rank.  The reference's loop drops a non-finite task loss per rank
+        (train/pretrain/multimodal.py:281-284), which DDP's fixed bucket order tolerates; this reducer issues a bucket's
+        collective as soon as its last expected contribution has been enqueued, so ranks that run different sets of
+        passes would issue different collective sequences.  Decide the drop together: ``if not red.agree_finite(l): skip``."""
+        ok = torch.stack([torch.isfinite(l.detach()).all() for l in losses]).all().to(torch.float32).reshape(1)
+        if self.world > 1:
+            ok = ok.to(self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(ok.item())
+
     def describe(self):
         """What a scaling run needs to check this reducer: the size of the communicator as the COMMUNICATOR reports it, the
         form of the exchange, bytes on the wire per step and rank (before the ring / tree factor)."""

@@ -12,6 +12,7 @@ The residual stream is fp32 (as under the reference's autocast), GEMM operands
 bf16 with fp32 accumulation, parameters fp32 masters with cached bf16 shadows.
 """
 import ctypes
+import sys
 
 import torch
 
@@ -59,7 +60,11 @@ class ShadowCache:
             if ent is not None and ent[0] == ver and ent[2] is not None:
                 continue
             w2 = p.detach().reshape(p.shape[0], -1)
-            if ent is not None and ent[1].shape == w2.shape and ent[2] is not None:
+            # in place only when nobody else holds the pair: a graph whose forward ran BEFORE the parameter update keeps its
+            # shadows for its input-gradient GEMMs (ctx.keep), and overwriting them would make that backward use the NEW
+            # weights (forward A, optimizer step, forward B, backward A).  The cache entry is the only other owner.
+            if (ent is not None and ent[1].shape == w2.shape and ent[2] is not None
+                    and sys.getrefcount(ent[1]) <= 2 and sys.getrefcount(ent[2]) <= 2):
                 w, wt = ent[1], ent[2]
             else:
                 w = torch.empty(w2.shape, dtype=torch.bfloat16, device=p.device)

@@ -248,8 +248,12 @@ class ZeroAdam:
         # every rank's updated slice -> every rank's full flat parameters (in place: the slice is the rank's
         # own chunk of the output buffer)
         if red.world > 1:
-            for pt in self.parts:       # the same buckets on every rank: routing is static, prepare() walks the same graph
-                if getattr(pt.bucket, 'shard32', None) is None or not getattr(pt.bucket, 'has_grad', False):
+            # EVERY partitioned bucket is gathered, stepped in this window or not: whether a bucket received a gradient is
+            # rank-local knowledge (bucket.has_grad), and a collective issued by some ranks only hangs the job; gathering
+            # an unchanged slice is a no-op in value.  (Ranks must still agree on which PASSES run -- see
+            # GradReducer.agree_finite -- because the reducer issues its collectives as the buckets become ready.)
+            for pt in self.parts:
+                if getattr(pt.bucket, 'shard32', None) is None:
                     continue
                 red.all_gather(pt.pflat, pt.pflat[pt.lo:pt.hi])
         # the parameters changed behind autograd's back: invalidate the engine's bf16 weight shadows
