@@ -388,8 +388,19 @@ def main():
                  'flops_per_launch': round(flops / n), 's_per_step': round(tsec / args.steps, 6)}
             # HBM bytes per launch: from the committed PMC passes of this same command (another run: flagged as such)
             try:
-                m = re.match(r'(gemm_[a-z_]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', sym)
                 epi = {'bias': 0, 'bias_gelu': 1, 'resid': 2, 'dgelu': 3, 'f32': 4, 'dual': 5, 'argmax': 6}
+                m16 = re.match(r'gemm_nt16_kernel<(\w+),Hx256>', sym)
+                if m16:
+                    # the 16x16x32 kernels of one epilogue run at several tile heights (one symbol per height in the
+                    # profile): launch-weighted mean of their bytes per launch
+                    pat16 = f'gemm_nt16_kernelIDF16bLi\\d+ELi{epi[m16.group(1)]}ELi\\dE'
+                    hits = [v for k, v in pmc['kernels'].items() if re.search(pat16, k)]
+                    tot = sum(v['launches'] for v in hits)
+                    r['traffic'] = round(sum((v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches'] for v in hits) / tot)
+                    r['traffic_measured_in_run'] = False
+                    r['traffic_source'] = os.path.relpath(tf, ROOT)
+                    return r
+                m = re.match(r'(gemm_[a-z_]+_kernel)<(?:(\w+),)?(\d+)x(\d+)>', sym)
                 if 'multi' in m.group(1):
                     pat = m.group(1)
                 else:

@@ -1583,7 +1583,8 @@ extern "C" int vlmo_profile_start(int max_records) {
 }
 
 // Stops recording and sums per tag (tag = epilogue id for gemm_nt, +16 when the 256x256 tile ran; 32 + epilogue for
-// conv; 64 / 72 for gemm_tn 128x128 / 256x256, 73 for gemm_tn_multi).  Call after the stream(s) have been synchronised.
+// conv; 48 + epilogue for the 256x128 tile; 64 / 72 for gemm_tn 128x128 / 256x256, 73 for gemm_tn_multi; 80 + epilogue for
+// the 16x16x32 kernels of any tile height).  Call after the stream(s) have been synchronised.
 extern "C" int vlmo_profile_stop(int ntags, double* ms, double* flops, int64_t* launches) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = false;
@@ -1687,7 +1688,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     if (tile >= 312 && tile <= 320) {
         // 16x16x32 MFMA, (16 * (tile - 300)) x 256 tile: bf16, plain GEMM (no convolution, no second segment)
         VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 / 312..320 are bf16, single-source");
-        ProfScope prof(epi + 16, 2.0 * Mtot * N * K, stream);
+        ProfScope prof(80 + epi, 2.0 * Mtot * N * K, stream);
         switch (tile) {
             case 312: return launch_nt16<bf16, 12>(epi, gp, stream);
             case 313: return launch_nt16<bf16, 13>(epi, gp, stream);

@@ -540,7 +540,7 @@ def block_bwd(desc):
     _check(lib().vlmo_block_bwd(ctypes.byref(desc), _stream()), 'vlmo_block_bwd')
 
 
-PROFILE_TAGS = 80
+PROFILE_TAGS = 96
 
 
 class TensorList(ctypes.Structure):
@@ -594,6 +594,8 @@ def profile_stop():
                 name = 'gemm_tn_kernel<%s>' % ('256x256' if t == 72 else '128x128')
             elif t == 73:
                 name = 'gemm_tn_multi_kernel<256x256>'
+            elif 80 <= t < 96:
+                name = f'gemm_nt16_kernel<{names.get(t - 80, t - 80)},Hx256>'
             elif 48 <= t < 64:
                 name = f'gemm_nt_kernel<{names.get(t - 48, t - 48)},256x128>'
             elif t >= 32:
