@@ -1663,7 +1663,8 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     // units (height 8 = 256 rows): 256x256 rounds x 8, 192x256 rounds x 6, 256x128x32 (two per CU, the epilogue of one under
     // the K loop of the other) rounds-of-512 x 8 x 0.9, 128x128 rounds-of-512 x 4.
     static const int nt16 = getenv("VLMO_NT16") ? atoi(getenv("VLMO_NT16")) : 1;       // measurement aid: 0 = off
-    if (nt16 && (tile == 0 || tile == 3 || tile == 4 || tile == 8) && dtype == VLMO_BF16 && !gp.g[0].k1 && !gp.g[0].ckw &&
+    static const int nt16_epis = getenv("VLMO_NT16_EPIS") ? atoi(getenv("VLMO_NT16_EPIS")) : 0xF;     // bit e: epilogue e may take these tiles
+    if (nt16 && ((nt16_epis >> epi) & 1) && (tile == 0 || tile == 3 || tile == 4 || tile == 8) && dtype == VLMO_BF16 && !gp.g[0].k1 && !gp.g[0].ckw &&
         (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU) && N >= 512 && K >= 512 &&
         Mtot * (long)N >= 150l * 65536 && tile_in < 0) {
         auto count = [&](int bm, int bn) {
