@@ -7,7 +7,18 @@
 #include <map>
 #include <vector>
 
+#include <stdlib.h>
 namespace {
+// VlmoEpilogue.relu bit 2: the fc1 epilogue saves GELU'(u) * dropout mask / (1 - p) in place of the pre-activation u, and the
+// GELU-derivative epilogue of dgrad_fc2 multiplies by it (measurement aid: VLMO_SAVE_GELU_DERIV=0 = the pre-activation path)
+int gelu_deriv_flag() {
+    static const int v = [] {
+        const char* e = getenv("VLMO_SAVE_GELU_DERIV");
+        return (e && e[0] == '0') ? 0 : 4;
+    }();
+    return v;
+}
+
 
 // fork / join events of the calling thread, one set per device (a process may drive several GPUs)
 struct Events {
@@ -106,6 +117,7 @@ extern "C" int vlmo_block_fwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
+        e.relu = gelu_deriv_flag();         // `u` holds GELU'(u) * mask / (1 - p): see the backward's EPI_DGELU
         a2[x] = bp(b->h, r0, hid, 2);
         w2[x] = b->w2[x];
         VlmoEpilogue& f = e2[x] = epi();
@@ -188,6 +200,7 @@ extern "C" int vlmo_block_bwd(const VlmoBlockDesc* b, hipStream_t st) {
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
+        e.relu = gelu_deriv_flag();
         af[x] = bp(b->du, r0, hid, 2);
         wf[x] = b->w1T[x];
         VlmoEpilogue& f = ef[x] = epi();
@@ -339,6 +352,7 @@ int block_dgrad_chain(const VlmoBlockDesc* b, hipStream_t st, Deferred& D, const
         e.drop_thresh = b->drop_thresh;
         e.inv_keep = b->inv_keep;
         e.seed = b->seed + 20 + 2 * x;
+        e.relu = gelu_deriv_flag();
         // fc1 bias gradient: the DGELU epilogue leaves column-sum partials (one row per 16 output rows, see
         // VlmoEpilogue.colpart) behind the (4 + experts) fold slots when the workspace has room; they join the block's
         // other column folds.  Else: a pass over du.

@@ -64,7 +64,9 @@ typedef struct VlmoEpilogue {
     const int32_t* row_index; /* [M] token -> scale group, or NULL          */
     const void* aux;        /* [M, ld2] pre-activation for VLMO_EPI_DGELU   */
     int32_t ldo, ld2;
-    int32_t relu;           /* bit 0: ReLU on the output (VLMO_EPI_BIAS); bit 1: ReLU on the INPUT activations (vlmo_conv2d_nhwc, f16) */
+    int32_t relu;           /* bit 0: ReLU on the output (VLMO_EPI_BIAS); bit 1: ReLU on the INPUT activations (vlmo_conv2d_nhwc, f16);
+                             * bit 2: VLMO_EPI_BIAS_GELU writes d h / d u = GELU'(u) * dropout mask / (1 - p) to `out` (not u),
+                             * and VLMO_EPI_DGELU takes exactly that as `aux`: out = acc * aux, no erf / hash in the backward */
     uint32_t drop_thresh;   /* round(p * 65536); 0 disables dropout         */
     float inv_keep;         /* 1 / (1 - p)                                  */
     float beta;

@@ -124,6 +124,35 @@ def test_gemm_nt_gelu_resid_dgelu_epilogues(tile):
     _close(dg, (A.float() @ B.float().t()) * a.grad, 1 / 128, 1e-2, 'dgelu')
 
 
+@pytest.mark.parametrize('tile', [-1, 0, 317])
+def test_gemm_nt_saved_gelu_derivative(tile):
+    """VlmoEpilogue.relu bit 2: the fc1 epilogue writes d h / d u = GELU'(u) * dropout mask / (1 - p) in place of the
+    pre-activation, the GELU-derivative epilogue multiplies by it -- the pair gives the same du as the pre-activation path
+    (bf16 rounding of the saved factor instead of the saved u), with the SAME dropout mask as the forward's h."""
+    M, N, K = 500, 384, 128
+    A, B = _rand(M, K, seed=4), _rand(N, K, scale=0.15, seed=5)
+    bias = _rand(N, seed=6, dtype=torch.float32) * 0.1
+    acc = A.float() @ B.float().t() + bias
+    drop = hip.drop_params(0.1, True)
+    for dp in ((0, 1.0), drop):
+        g = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        hh = torch.empty_like(g)
+        hip.gemm_nt(hip.EPI_BIAS_GELU, A, B, M, N, K, g, out2=hh, bias=bias, relu=4, drop=dp, seed=11, tile=tile)
+        a = acc.clone().requires_grad_(True)
+        F.gelu(a).backward(torch.ones_like(a))
+        keep = (hh != 0) | (g != 0)                 # the mask the forward applied: a dropped element is zero in BOTH outputs
+        scale = dp[1]
+        _close(hh, F.gelu(acc) * keep * scale, 1 / 128, 1e-2, 'h')
+        _close(g, a.grad * keep * scale, 1 / 128, 1e-2, 'saved derivative')
+        if dp[0]:
+            assert 0.05 < 1 - keep.float().mean().item() < 0.15
+        # backward: dh . W2^T-like product times the saved factor
+        A2, B2 = _rand(M, K, seed=14), _rand(N, K, scale=0.15, seed=15)
+        du = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(hip.EPI_DGELU, A2, B2, M, N, K, du, aux=g, relu=4, tile=tile)
+        _close(du, (A2.float() @ B2.float().t()) * g.float(), 1 / 128, 1e-2, 'du')
+
+
 @pytest.mark.parametrize('M', [500, 1000, 77])
 def test_gemm_nt_dgelu_column_partials(M):
     """VlmoEpilogue.colpart: [ceil(M/16), N] fp32, EVERY row written by exactly one epilogue pass (sums of the pass's rows
