@@ -98,7 +98,10 @@ __device__ __forceinline__ void pin4(f32x4& v) {
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
-template <typename T, int EPI>
+// GD: VlmoEpilogue.relu bit 2 (saved GELU derivative, see EPI_BIAS_GELU below) known at compile time (0 / 1) or read from the
+// descriptor (-1).  The 16x16x32 kernels instantiate both: with the choice at run time each unrolled epilogue pass carried
+// both bodies and the fc1 kernel grew to 110 KB of instructions.
+template <typename T, int EPI, int GD = -1>
 __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, int gn, f32x4 v, f32x4 bias4,
                                            f32x4 gamma4, f32x4 ext, float rs, bool ok) {
     // ALL arithmetic runs unconditionally (rows past M compute on clamped inputs) and only the stores sit under
@@ -125,7 +128,7 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, in
         if (ok) *(f32x4*)o.at<float>(e.out) = v;
     } else if constexpr (EPI == EPI_BIAS_GELU) {
         f32x4 h;
-        if (e.relu & 4) {
+        if (GD >= 0 ? GD != 0 : (e.relu & 4) != 0) {
             // `out` receives d h / d u = GELU'(u) * dropout mask / (1 - p) instead of the pre-activation u: the backward's
             // GELU-derivative epilogue (EPI_DGELU with the same bit) is then ONE multiply per element -- no erf, no
             // exponential, no dropout hash (27.8 -> ~6 vector instructions per element there for ~5 more here: the
@@ -196,7 +199,7 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmNT& p, int gmb, int row, in
         pin4(v);
         if (ok) store4<T>(o.at<T>(e.out), v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_DGELU) {
-        if (e.relu & 4) {
+        if (GD >= 0 ? GD != 0 : (e.relu & 4) != 0) {
             v *= ext;       // aux holds GELU'(u) * mask / (1 - p), written by the forward's EPI_BIAS_GELU with the same bit
         } else {
 #pragma unroll
@@ -738,7 +741,7 @@ template <int... Is, typename F> __device__ __forceinline__ void static_for(std:
 // the split, and the tile height moves in 16-row steps (208 rows: 243 tiles for N = 768 at M = 16 704; 272 rows: 744 tiles
 // = three rounds for N = 3 072; 304 rows: 495 tiles = two rounds for N = 2 304).  Everything from the accumulators on is
 // written once and instantiated per wave group (`body`); both copies execute the same barrier sequence.
-template <typename T, int H16, int EPI, int SCHED = 1>
+template <typename T, int H16, int EPI, int SCHED = 1, int GD = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp) {
     typedef typename Elem<T>::v8 v8;
     constexpr int TMA = (H16 + 1) / 2, TMB = H16 / 2;
@@ -968,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
             for (int it = 0; it < NIT; ++it) {
                 const int row = it * RPI + rrow;
                 const bool ok = gmb + row < p.M && col_ok;
-                const f32x4 w = epilogue4<T, EPI>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
+                const f32x4 w = epilogue4<T, EPI, GD>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
                 if constexpr (EPI == EPI_DGELU) {
     #pragma unroll
                     for (int j = 0; j < 4; ++j) csum[j] += ok ? w[j] : 0.f;
@@ -1529,16 +1532,32 @@ int launch_nt16(int epi, GemmNTGroups& p, hipStream_t st) {
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
     dim3 grid(tiles), block(512);
     bool known = true;
+    // saved-GELU-derivative variant (VlmoEpilogue.relu bit 2): one choice per launch, every group must agree
+    const bool gd = (p.g[0].e.relu & 4) != 0;
+    for (int q = 1; q < p.ngroups; ++q)
+        if (((p.g[q].e.relu & 4) != 0) != gd) {
+            vlmo_set_error("vlmo_gemm_nt_grouped: the groups of a launch must agree on VlmoEpilogue.relu bit 2");
+            return -1;
+        }
 #define VLMO_LAUNCH16(E)                                                                        \
     case E:                                                                                     \
     if constexpr (((EMASK >> E) & 1u) == 0) {                                                   \
         known = false;                                                                          \
     } else {                                                                                    \
-        auto k = gemm_nt16_kernel<T, H16, E, SCHED>;                                   \
-        static DeviceOnce attr_set;                                                             \
-        if (LDS > 65536 && attr_set.first())                                                    \
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-        hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                         \
+        constexpr bool HAS_GD = (E == EPI_BIAS_GELU || E == EPI_DGELU);                         \
+        if (HAS_GD && gd) {                                                                     \
+            auto k = gemm_nt16_kernel<T, H16, E, SCHED, HAS_GD ? 1 : 0>;                        \
+            static DeviceOnce attr_set;                                                         \
+            if (LDS > 65536 && attr_set.first())                                                \
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+            hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                     \
+        } else {                                                                                \
+            auto k = gemm_nt16_kernel<T, H16, E, SCHED, 0>;                                     \
+            static DeviceOnce attr_set;                                                         \
+            if (LDS > 65536 && attr_set.first())                                                \
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+            hipLaunchKernelGGL(k, grid, block, LDS, st, p);                                     \
+        }                                                                                       \
     } break;
     switch (epi) {
         VLMO_LAUNCH16(EPI_BIAS)
