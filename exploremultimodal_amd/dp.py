@@ -176,7 +176,11 @@ class GradReducer:
         # real bucket's size at start-up and keep the fastest.  Explicit choices (VLMO_DP_COLLECTIVE, comm=...) are kept.
         self.tuned = None
         if self.world > 1 and os.environ.get('VLMO_DP_AUTOTUNE', '1') != '0':
-            self.autotune(try_native=(comm is None and 'VLMO_DP_COMM' not in os.environ and self.on_gpu),
+            # the library's own communicator joins the candidates only on request (VLMO_DP_TRY_NATIVE=1): it has run at
+            # world size 1 only, and a second RCCL communicator whose creation went wrong on one rank would hang the job
+            # at start-up -- not a risk to take by default for ~0.3 ms per step
+            self.autotune(try_native=(comm is None and 'VLMO_DP_COMM' not in os.environ and self.on_gpu
+                                      and os.environ.get('VLMO_DP_TRY_NATIVE', '0') == '1'),
                           try_collective='VLMO_DP_COLLECTIVE' not in os.environ,
                           try_dtype=self._auto_dtype and self.on_gpu)
         elif self._auto_dtype and self.world == 1:
