@@ -105,7 +105,8 @@ def test_large_full_objective_zero2_step():
         for n in wr:
             upd = (wr[n] - inits[n]).abs().max().item()
             err = (wz[n] - wr[n]).abs().max().item()
-            assert err <= 1e-5 * upd + 1e-9, (n, err, upd)
+            ulp = 2.0 ** -23 * wr[n].abs().max().item()          # the two clip coefficients differ in their last bit: one ulp of w
+            assert err <= 1e-5 * upd + 2 * ulp + 1e-9, (n, err, upd, ulp)
     finally:
         for r in reds:
             r.close()

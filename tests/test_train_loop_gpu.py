@@ -186,7 +186,8 @@ def test_zero2_step_equals_replicated_step_rccl_single_rank():
             a, b, w0 = results['zero2'][n], results['replicated'][n], inits[n]
             upd = (b - w0).abs().max().item()
             err = (a - b).abs().max().item()
-            assert err <= 1e-5 * upd + 1e-9, (n, err, upd)
+            ulp = 2.0 ** -23 * b.abs().max().item()              # the two clip coefficients differ in their last bit: one ulp of w
+            assert err <= 1e-5 * upd + 2 * ulp + 1e-9, (n, err, upd, ulp)
     finally:
         for r in reds:
             r.close()
