@@ -753,6 +753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
     static_assert(NW * 32 * 64 * 4 <= 2 * STAGE, "epilogue LDS must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    const uint64_t t_kernel = (SCHED & 8) ? __builtin_amdgcn_s_memtime() : 0;      // diagnostic build only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -886,6 +887,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
             if constexpr (PROBE) {
                 t_begin = t_prev = __builtin_amdgcn_s_memtime();
                 r_begin = __builtin_amdgcn_s_memrealtime();
+                // o[7] of the record: cycles from the kernel's first instruction to here (set-up, first DMA issued and landed)
+                if (p.e.colpart && lane == 0)
+                    ((uint64_t*)p.e.colpart)[((size_t)blockIdx.x * NW + wave) * 8 + 7] = t_begin - t_kernel;
             }
             for (int kt = 0; kt < nk; ++kt) {
                 const char* cur = smem + (kt & 1) * STAGE;
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
                 if (p.e.colpart && lane == 0) {
                     uint64_t* o = (uint64_t*)p.e.colpart + ((size_t)blockIdx.x * NW + wave) * 8;
                     o[0] = seg_sum[0], o[1] = seg_sum[1], o[2] = seg_sum[2], o[3] = seg_sum[3];
-                    o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)nk, o[7] = (uint64_t)__builtin_amdgcn_s_getreg(0xf814) /* XCC_ID */;
+                    o[4] = t_end - t_begin, o[5] = r_end - r_begin, o[6] = (uint64_t)nk;
                 }
             }
         }

@@ -30,5 +30,8 @@ for tile in (908, 909):
         seg = np.median(r[:, grp, 0:4].reshape(-1, 4), axis=0) / nk
         tot = np.median(r[:, grp, 4]) / nk
         clk = np.median(r[:, grp, 4] / np.maximum(r[:, grp, 5], 1)) * 100e6 / 1e9
+        pro = np.median(r[:, grp, 7])
+        print(f'      prologue (kernel start -> K loop) {pro:7.0f} cycles = {pro / clk / 1e3:5.2f} us; K loop {np.median(r[:, grp, 4]):8.0f} cycles = '
+              f'{np.median(r[:, grp, 4]) / clk / 1e3:6.2f} us')
         print(f'sched {tile - 908} {name}: cycles per K-tile: read0 {seg[0]:6.0f}  mfma0 {seg[1]:6.0f}  read1 {seg[2]:6.0f}  mfma1 {seg[3]:6.0f}  '
               f'total {tot:6.0f}  ({nk} K-tiles)  in-kernel clock {clk:.2f} GHz', flush=True)
