@@ -29,9 +29,9 @@ for tile in [int(t) for t in os.environ.get('PROBE_TILES', '3,0').split(',')]:
         A = torch.randn(M, K, device=dev).bfloat16()
         B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         t = timeit(lambda: hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out, bias=bias, tile=tile))
-        tiles = ((M + 255) // 256) * ((N + 255) // 256) if tile == 3 else ((M + 127) // 128) * ((N + 127) // 128)
+        bm = 16 * (tile - 300) if tile >= 312 else (128 if tile == 0 else 256)       # 312..320: the 16x16x32 kernels
+        bn = 128 if tile == 0 else 256
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         slots = 512 if tile == 0 else 256
-        if tile != 0:
-            tiles = ((M + 255) // 256) * ((N + 255) // 256)
         print(f'tile={tile} M={M} N={N} K={K:5d}: {t:7.1f} us  tiles {tiles} = {tiles / slots:.2f} rounds  '
               f'{t / (tiles / slots):6.1f} us per round  {2 * M * N * K / t / 1e6:7.1f} TF/s', flush=True)
