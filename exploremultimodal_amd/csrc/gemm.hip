@@ -1043,7 +1043,7 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row
 // is still made of whole 256-byte row pieces (the NT kernel cannot do this: its K runs along the rows, half a K-tile is
 // half of every cache line).  Slice h + 3 is issued in the read segment of slice h -- four DMA instructions per wave
 // and segment instead of eight in every other one -- and waited for with a counted vmcnt that leaves two slices in flight.
-template <typename T, int BM, int BN, int WM, int WN, bool PP = false, bool PROBE = false, bool R4 = false>
+template <typename T, int BM, int BN, int WM, int WN, bool PP = false, bool PROBE = false, bool R4 = false, bool M16 = false>
 __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
     typedef typename Elem<T>::v8 v8;
     typedef typename Elem<T>::v4 v4;
@@ -1126,6 +1126,132 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {
             glds16((const T*)p.B + (size_t)gr * p.ldb + b_off[i], s + A_BYTES + (i * NW + wave) * 1024);
         }
     };
+
+    if constexpr (M16) {
+        // ---- v_mfma_f32_16x16x32 variant of the slice ring (round 4; the NT kernels' port measured +8.6 % at the MFMA-paced
+        // probe shape): a 32-token slice is ONE k-step.  Operand lane l holds column l & 15, tokens 8 (l >> 4) + j: two
+        // transposed reads of 4 tokens x 16 columns each (tests/test_lds_layouts.py::test_gemm_tn16_fragments: right elements,
+        // conflict-free on the unchanged image).  C/D: column = l & 15, row = 4 (l >> 4) + register.
+        static_assert(PP && R4 && WM == 2, "16x16x32: slice ring, ping-pong schedule");
+        constexpr int T16M = BM / WM / 16, T16N = BN / WN / 16;
+        f32x4 acc[T16M][T16N];
+#pragma unroll
+        for (int i = 0; i < T16M; ++i)
+#pragma unroll
+            for (int j = 0; j < T16N; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, l15 = lane & 15;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+        uint32_t a_rd[2][T16M], b_rd[2][T16N];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int m0 = 8 * g + 4 * half + q;
+            const int sw = tn_swz(m0);
+#pragma unroll
+            for (int t = 0; t < T16M; ++t) {
+                const int na = wm * (BM / WM) + t * 16 + 4 * pp;
+                a_rd[half][t] = lds0 + (na >> 7) * SUB + m0 * 256 + ((((na & 127) >> 3) ^ sw) << 4) + (na & 7) * 2;
+            }
+#pragma unroll
+            for (int t = 0; t < T16N; ++t) {
+                const int nb = wn * (BN / WN) + t * 16 + 4 * pp;
+                b_rd[half][t] = lds0 + A_BYTES + (nb >> 7) * SUB + m0 * 256 + ((((nb & 127) >> 3) ^ sw) << 4) + (nb & 7) * 2;
+            }
+        }
+        v8 af[T16M], bf[T16N];
+        typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+        auto tr = [&](uint32_t addr) -> v4 {        // inline asm: see the 32x32x16 path below (hipcc waits vmcnt(0) behind the builtin)
+            u32x2 r;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+            return __builtin_bit_cast(v4, r);
+        };
+        auto read_slice = [&](int slot) {
+            const uint32_t so = (uint32_t)slot * STAGE;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int t = 0; t < T16N; ++t) {
+                    const v4 vb = tr(b_rd[half][t] + so);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[t][4 * half + e] = vb[e];
+                }
+#pragma unroll
+                for (int t = 0; t < T16M; ++t) {
+                    const v4 va = tr(a_rd[half][t] + so);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[t][4 * half + e] = va[e];
+                }
+            }
+        };
+        auto mfma_slice = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < T16M; ++i)
+#pragma unroll
+                for (int j = 0; j < T16N; ++j) acc[i][j] = Elem<T>::mfma16(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const int ns = 2 * (kt1 - kt0), s0 = 2 * kt0;
+        auto wait_next = [&](int h) {
+            if (h + 3 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (h + 2 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        stage(0, s0);
+        stage(1, s0 + 1);
+        if (ns > 2) stage(2, s0 + 2);
+        wait_next(-1);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) bar();
+        for (int h_ = 0; h_ < ns; ++h_) {
+            read_slice(h_ & 3);
+            if (h_ + 3 < ns) stage((h_ + 3) & 3, s0 + h_ + 3);
+            if (wm == 1 && h_ + 1 < ns) wait_next(h_);
+            bar();
+            mfma_slice();
+            if (wm == 0 && h_ + 1 < ns) wait_next(h_);
+            bar();
+        }
+        if (wm == 0) bar();
+        // epilogue: lane = output column (16 per tile), registers = four consecutive output rows
+#pragma unroll
+        for (int i = 0; i < T16M; ++i)
+#pragma unroll
+            for (int j = 0; j < T16N; ++j) {
+                const int gn = n2_0 + wn * (BN / WN) + j * 16 + l15;
+                const int gm0 = n1_0 + wm * (BM / WM) + i * 16 + 4 * g;
+                const bool okn = gn < p.N2;
+                if (!p.slab && p.mode == TN_ACCUM) {
+                    float old[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) old[r] = (okn && gm0 + r < p.N1) ? p.C[(size_t)(gm0 + r) * p.ldc + gn] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (okn && gm0 + r < p.N1) p.C[(size_t)(gm0 + r) * p.ldc + gn] = old[r] + p.alpha * acc[i][j][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gm = gm0 + r;
+                        if (gm < p.N1 && okn) {
+                            float* c = p.C + (size_t)gm * p.ldc + gn;
+                            if (p.slab)
+                                p.slab[((size_t)split * p.N1 + gm) * p.N2 + gn] = acc[i][j][r];
+                            else if (p.mode == TN_STORE)
+                                *c = p.alpha * acc[i][j][r];
+                            else
+                                atomicAdd(c, p.alpha * acc[i][j][r]);
+                        }
+                    }
+                }
+            }
+        return;
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1432,7 +1558,7 @@ struct GemmTNMulti {
     GemmTN p[MAX_TN_PROBS];
     uint16_t order[MAX_TN_ORDER];
 };
-template <typename T, bool R4 = false>
+template <typename T, bool R4 = false, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti mp) {
     const uint32_t code = mp.order[blockIdx.x];
     if (code == TN_NOP) return;
@@ -1451,7 +1577,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_multi_kernel(const GemmTNMulti
     p.alpha = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.alpha)));
     p.slab = nullptr;
     p.mode = __builtin_amdgcn_readfirstlane(q.mode);
-    gemm_tn_body<T, 256, 256, 2, 4, true, false, R4>(p, lid_in);
+    gemm_tn_body<T, 256, 256, 2, 4, true, false, R4, M16>(p, lid_in);
 }
 
 // C[r, c] += alpha * sum_s slab[s, r, c]   (one float4 per thread)
@@ -1860,6 +1986,14 @@ TnPlan tn_plan(int M, int N1, int N2, int splits_req, int force_tile) {
 
 namespace {
 // measurement aid: VLMO_TN_RING4=0 selects the two-buffer 64-token staging of the bf16 ping-pong weight-gradient kernels
+// measurement aid: VLMO_TN_MFMA16=1 runs the batched weight-gradient launch on v_mfma_f32_16x16x32 (default: see DESIGN.md)
+bool tn_mfma16() {
+    static const bool v = [] {
+        const char* e = getenv("VLMO_TN_MFMA16");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
 bool tn_ring4() {
     static const bool v = [] {
         const char* e = getenv("VLMO_TN_RING4");
@@ -1955,6 +2089,7 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         constexpr int LDS = 2 * 4 * 64 * 256;
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<bf16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<f16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
     for (int q0 = 0, nq = 0; q0 < n; q0 += nq) {
@@ -2046,6 +2181,8 @@ extern "C" int vlmo_gemm_tn_multi(int dtype, const VlmoTnProblem* probs, int n, 
         constexpr int LDS = 2 * 4 * 64 * 256;
         if (dtype == VLMO_F16)
             hipLaunchKernelGGL((gemm_tn_multi_kernel<f16, true>), dim3(t), dim3(512), LDS, stream, mp);
+        else if (tn_ring4() && tn_mfma16())
+            hipLaunchKernelGGL((gemm_tn_multi_kernel<bf16, true, true>), dim3(t), dim3(512), LDS, stream, mp);
         else if (tn_ring4())
             hipLaunchKernelGGL((gemm_tn_multi_kernel<bf16, true>), dim3(t), dim3(512), LDS, stream, mp);
         else
