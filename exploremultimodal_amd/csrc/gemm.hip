@@ -18,6 +18,7 @@
 #include "vlmo_hip.h"
 #include <stdlib.h>
 #include <mutex>
+#include <string>
 #include <vector>
 #include <utility>
 #include <type_traits>
@@ -1839,9 +1840,16 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     // the K loop of the other) rounds-of-512 x 8 x 0.9, 128x128 rounds-of-512 x 4.
     static const int nt16 = getenv("VLMO_NT16") ? atoi(getenv("VLMO_NT16")) : 1;       // measurement aid: 0 = off
     static const int nt16_epis = getenv("VLMO_NT16_EPIS") ? atoi(getenv("VLMO_NT16_EPIS")) : 0xF;     // bit e: epilogue e may take these tiles
+    // at EQUAL tile height the 16x16x32 kernel is 4 - 8 % faster than the 32x32x16 ones (DMA issued in the read segment;
+    // tools/nt16_bench.py at M = 12 608 / 33 408, profiles/r04_nt16_bigM.txt), so a tie in the model goes to it; problems from
+    // 40 output tiles of 256 x 256 up (M = 12 608 at N = 768: 42 -> 36 us).  In-session A/Bs of the full four-loss objective
+    // (B = 32, merged passes): (97 %, 150 tiles) -> (102, 100) -1.0 ms, -> (106, 40) another -1.3 ms, (110, 16) no further
+    // change; VLMo-Large -0.3 ms (its N = 1 024 GEMMs at 8 352 rows were below the old threshold), VLMo-Base unchanged.
+    static const int nt16_tie = getenv("VLMO_NT16_TIE") ? atoi(getenv("VLMO_NT16_TIE")) : 106;        // measurement aid: percent of the old tile's cost
+    static const long nt16_min = getenv("VLMO_NT16_MIN") ? atol(getenv("VLMO_NT16_MIN")) : 40;
     if (nt16 && ((nt16_epis >> epi) & 1) && (tile == 0 || tile == 3 || tile == 4 || tile == 8) && dtype == VLMO_BF16 && !gp.g[0].k1 && !gp.g[0].ckw &&
         (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU) && N >= 512 && K >= 512 &&
-        Mtot * (long)N >= 150l * 65536 && tile_in < 0) {
+        Mtot * (long)N >= nt16_min * 65536l && tile_in < 0) {
         auto count = [&](int bm, int bn) {
             long t = 0;
             for (int q = 0; q < gp.ngroups; ++q) t += (long)((gp.g[q].M + bm - 1) / bm) * ((N + bn - 1) / bn);
@@ -1858,9 +1866,24 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             const double c = (double)((count(16 * h16, 256) + 255) / 256) * h16 * 0.5;
             if (c < bc) bc = c, best = h16;
         }
-        if (bc <= cur * 0.97) tile = 300 + best;
+        if (bc * 100 <= cur * nt16_tie) tile = 300 + best;
     }
     if (tile >= 106 && tile <= 110) tile = 300 + 2 * (tile - 100);      // (32 * (tile - 100)) rows = an even H16
+    static const bool trace = getenv("VLMO_NT_TRACE") != nullptr;       // measurement aid: every distinct (epilogue, shape, tile) once
+    if (trace) {
+        static std::mutex mu;
+        static std::vector<std::string> seen;
+        char buf[256];
+        int o = snprintf(buf, sizeof buf, "vlmo_gemm_nt: epi %d N %d K %d tile %d (asked %d) M", epi, N, K, tile, tile_in);
+        for (int q = 0; q < gp.ngroups && o < 230; ++q) o += snprintf(buf + o, sizeof buf - o, " %d", gp.g[q].M);
+        std::lock_guard<std::mutex> lk(mu);
+        bool have = false;
+        for (auto& t : seen) have |= (t == buf);
+        if (!have) {
+            seen.emplace_back(buf);
+            fprintf(stderr, "%s\n", buf);
+        }
+    }
     if (tile >= 312 && tile <= 320) {
         // 16x16x32 MFMA, (16 * (tile - 300)) x 256 tile: bf16, plain GEMM (no convolution, no second segment)
         VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 / 312..320 are bf16, single-source");
