@@ -237,6 +237,24 @@ __device__ __forceinline__ f32x4 epilogue_ext(const GemmNT& p, int gmb, int rowc
     }
 }
 
+// The same row segment as it comes from memory (no conversion: a conversion would be the load's first user and pin an
+// s_waitcnt right behind it), for epilogues that request the NEXT pass's segments before working on the current one.
+template <typename T, int EPI> struct ExtRaw { typedef f32x4 type; };
+template <typename T> struct ExtRaw<T, EPI_DGELU> { typedef typename Elem<T>::v4 type; };
+template <typename T, int EPI>
+__device__ __forceinline__ typename ExtRaw<T, EPI>::type epilogue_ext_raw(const GemmNT& p, int gmb, int rowc, int gnc) {
+    if constexpr (EPI == EPI_DGELU) {
+        const RowAddr o2{(size_t)gmb * p.e.ld2, (uint32_t)(rowc * p.e.ld2 + gnc)};
+        return NT_LD((const typename Elem<T>::v4*)o2.at<T>(p.e.aux));
+    } else {
+        return epilogue_ext<T, EPI>(p, gmb, rowc, gnc);
+    }
+}
+template <typename T> __device__ __forceinline__ f32x4 ext_f32(f32x4 v) { return v; }
+template <typename T> __device__ __forceinline__ f32x4 ext_f32(typename Elem<T>::v4 v) {
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
 // The rebuilt pointer is typed GLOBAL before it decays to a generic one: an integer -> generic pointer would make every
 // access through it a FLAT instruction (which counts on vmcnt AND lgkmcnt, so each epilogue store was followed by
 // `s_waitcnt vmcnt(0) lgkmcnt(0)` before the next LDS access: ~10 us of serialised store round trips per 256x256 tile).
@@ -939,13 +957,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
         if (p.e.bias) bias4 = *(const f32x4*)(p.e.bias + gnc);
         if (EPI == EPI_RESID && p.e.gamma) gamma4 = *(const f32x4*)(p.e.gamma + gnc);
-        auto epi_pass = [&](auto nr_c, auto i0_c) __attribute__((always_inline)) {
-            constexpr int NR = decltype(nr_c)::value, I0 = decltype(i0_c)::value;
+        // What a pass needs from global memory besides the accumulators (GELU-derivative factor / fp32 residual rows, drop-path
+        // scales) is requested ONE PASS AHEAD where the registers allow it: a wave's passes were otherwise 4 - 5 serialised
+        // load round trips (request -> LDS transpose -> wait -> arithmetic -> stores).  (Deeper does not pay: see DESIGN.md.)
+        typedef typename ExtRaw<T, EPI>::type XR;
+        constexpr int NP = (TM + 1) / 2;
+        constexpr bool AHEAD = (EPI == EPI_DGELU) || (EPI == EPI_RESID && TM <= 7);      // 8 tile rows + two passes of fp32 rows: spills
+        XR xr[2][8];
+        float rsv[2][8];
+        auto epi_load = [&](auto pi_c) __attribute__((always_inline)) {
+            constexpr int P = decltype(pi_c)::value, I0 = 2 * P, NR = (I0 + 2 <= TM) ? 2 : 1;
             constexpr int NIT = NR * 16 / RPI;
             const int gmb = __builtin_amdgcn_readfirstlane(m0 + ROW0 + I0 * 16);
             const int gmbc = min(gmb, p.M - 1);
-            f32x4 ext[NIT];
-            float rs[NIT];
             int ridx[NIT];
     #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -955,9 +979,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
     #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int rowc = min(it * RPI + rrow, p.M - 1 - gmbc);
-                ext[it] = epilogue_ext<T, EPI>(p, gmbc, rowc, gnc);
-                rs[it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
+                xr[P & 1][it] = epilogue_ext_raw<T, EPI>(p, gmbc, rowc, gnc);
+                rsv[P & 1][it] = (EPI == EPI_RESID && p.e.row_scale) ? p.e.row_scale[ridx[it]] : 1.f;
             }
+        };
+        auto epi_pass = [&](auto pi_c) __attribute__((always_inline)) {
+            constexpr int P = decltype(pi_c)::value, I0 = 2 * P, NR = (I0 + 2 <= TM) ? 2 : 1;
+            constexpr int NIT = NR * 16 / RPI;
+            const int gmb = __builtin_amdgcn_readfirstlane(m0 + ROW0 + I0 * 16);
+            if constexpr (!AHEAD) epi_load(pi_c);
             // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register
     #pragma unroll
             for (int ii = 0; ii < NR; ++ii)
@@ -971,12 +1001,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
             f32x4 v[NIT];
     #pragma unroll
             for (int it = 0; it < NIT; ++it) v[it] = *(const f32x4*)(ep + (it * RPI + rrow) * ROWF + rcol);
+            if constexpr (AHEAD && P + 1 < NP) epi_load(std::integral_constant<int, P + 1>{});
             f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = it * RPI + rrow;
                 const bool ok = gmb + row < p.M && col_ok;
-                const f32x4 w = epilogue4<T, EPI, GD>(p, gmb, row, gn, v[it], bias4, gamma4, ext[it], rs[it], ok);
+                const f32x4 w = epilogue4<T, EPI, GD>(p, gmb, row, gn, v[it], bias4, gamma4, ext_f32<T>(xr[P & 1][it]), rsv[P & 1][it], ok);
                 if constexpr (EPI == EPI_DGELU) {
     #pragma unroll
                     for (int j = 0; j < 4; ++j) csum[j] += ok ? w[j] : 0.f;
@@ -1001,10 +1032,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt16_kernel(const GemmNTGroups gp
                 }
             }
         };
-        static_for(std::make_integer_sequence<int, TM / 2>{}, [&](auto pi) __attribute__((always_inline)) {
-            epi_pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * decltype(pi)::value>{});
+        if constexpr (AHEAD) epi_load(std::integral_constant<int, 0>{});
+        static_for(std::make_integer_sequence<int, NP>{}, [&](auto pi) __attribute__((always_inline)) {
+            epi_pass(std::integral_constant<int, decltype(pi)::value>{});
         });
-        if constexpr (TM & 1) epi_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, TM - 1>{});
     };
     if (wm == 0)
         body(std::integral_constant<int, TMA>{}, std::integral_constant<int, 0>{});
