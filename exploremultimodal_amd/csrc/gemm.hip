@@ -1847,13 +1847,20 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             for (int q = 0; q < gp.ngroups; ++q) t256 += (long)((gp.g[q].M + 255) / 256) * ((N + 255) / 256);
             if (t256 <= 256) tile = 3;
         }
+        // fewer than 128 tiles of 256x256 (the text-only pass of the four-loss objective: 2 048 rows) leave most CUs without
+        // work whatever the reduction depth: 128x128 tiles, one or two per CU (tools/nt16_bench.py --M 2048, N = 768, K = 3 072:
+        // 76 us with 24 tiles of 256x256, 62 with 192x256, 36.5 with 96 of 128x128)
+        long t256_all = 0;
+        for (int q = 0; q < gp.ngroups; ++q) t256_all += (long)((gp.g[q].M + 255) / 256) * ((N + 255) / 256);
+        const bool few_tiles = t256_all <= 128;
+        if (few_tiles) tile = 0;
         static const bool tile4 = !getenv("VLMO_NT_TILE4") || atoi(getenv("VLMO_NT_TILE4")) != 0;     // measurement aid
         if (tile4 && tile == 0 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && K <= 1024 && N >= 2048 && Mtot >= 4096)
             tile = 4;
         // 192-row ping-pong tiles when they cut the dispatch rounds (VLMo-Large at 32 pairs: M = 8 352 = 32.6 x 256, so
         // N = 1 024 is 132 tiles of 256x256 on 256 CUs but 176 tiles of 192x256, each 3/4 of the work)
         static const int t192 = getenv("VLMO_NT_TILE192") ? atoi(getenv("VLMO_NT_TILE192")) : 2;       // measurement aid: 0 off, 1 only in place of 256x256, 2 in place of any
-        if (t192 && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU) && K >= 1024 &&
+        if (t192 && !few_tiles && dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU) && K >= 1024 &&
             (tile == 3 || t192 == 2)) {
             long t256 = 0, t192n = 0;
             for (int q = 0; q < gp.ngroups; ++q) {
@@ -1864,11 +1871,14 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             if (e192 * 10 <= e256 * 9) tile = 8;
         }
     }
-    // 16x16x32 tiles of (16 * H16) x 256, H16 = 12 .. 20: the height is chosen so that the tiles fill whole dispatch rounds of
-    // the 256 CUs.  Cost model (tools/nt16_bench.py, M = 16 704: the measured times of one shape are proportional to it
-    // within 4 %): a launch costs rounds x tile height, rounds = ceil(tiles / 256).  The tiles picked above cost, in the same
-    // units (height 8 = 256 rows): 256x256 rounds x 8, 192x256 rounds x 6, 256x128x32 (two per CU, the epilogue of one under
-    // the K loop of the other) rounds-of-512 x 8 x 0.9, 128x128 rounds-of-512 x 4.
+    // 16x16x32 tiles of (16 * H16) x 256, H16 = 9 .. 20: the height is chosen so that the tiles fill whole dispatch rounds of
+    // the 256 CUs.  Cost model (tools/nt16_bench.py at M = 2 048 ... 33 408, profiles/r04_nt16_*.txt): a launch costs
+    // rounds x (H16 + 26), rounds = ceil(tiles / 256) -- a K-tile of a (16 H16) x 256 tile stages 16 (H16 + 16) rows through the
+    // CU's fill path, and a tile-round carries a fixed part worth ~10 more (prologue, epilogue, launch): 144 against 192 rows
+    // measured 0.92 - 0.94 x (model 0.92), 160 against 208 0.93 - 0.95 (0.92), three rounds of 272 against four of 256 0.87
+    // (0.77).  The tiles picked above cost, in the same units: 256x256 rounds x 42, 192x256 rounds x 38, 256x128x32 (two per
+    // CU, the epilogue of one under the K loop of the other) rounds-of-512 x 38, 128x128 rounds-of-512 x 21 (16 when every
+    // tile has a CU to itself).
     static const int nt16 = getenv("VLMO_NT16") ? atoi(getenv("VLMO_NT16")) : 1;       // measurement aid: 0 = off
     static const int nt16_epis = getenv("VLMO_NT16_EPIS") ? atoi(getenv("VLMO_NT16_EPIS")) : 0xF;     // bit e: epilogue e may take these tiles
     // at EQUAL tile height the 16x16x32 kernel is 4 - 8 % faster than the 32x32x16 ones (DMA issued in the read segment;
@@ -1887,14 +1897,14 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             return t;
         };
         double cur;
-        if (tile == 3) cur = (double)((count(256, 256) + 255) / 256) * 8;
-        else if (tile == 8) cur = (double)((count(192, 256) + 255) / 256) * 6;
-        else if (tile == 4) cur = (double)((count(256, 128) + 511) / 512) * 8 * 0.9;
-        else cur = (double)((count(128, 128) + 511) / 512) * 4;
+        if (tile == 3) cur = (double)((count(256, 256) + 255) / 256) * 42;
+        else if (tile == 8) cur = (double)((count(192, 256) + 255) / 256) * 38;
+        else if (tile == 4) cur = (double)((count(256, 128) + 511) / 512) * 38;
+        else cur = count(128, 128) <= 256 ? 16.0 : (double)((count(128, 128) + 511) / 512) * 21;
         int best = 0;
         double bc = 1e30;
-        for (int h16 = 12; h16 <= 20; ++h16) {
-            const double c = (double)((count(16 * h16, 256) + 255) / 256) * h16 * 0.5;
+        for (int h16 = 9; h16 <= 20; ++h16) {
+            const double c = (double)((count(16 * h16, 256) + 255) / 256) * (h16 + 26);
             if (c < bc) bc = c, best = h16;
         }
         if (bc * 100 <= cur * nt16_tie) tile = 300 + best;
@@ -1915,11 +1925,14 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
             fprintf(stderr, "%s\n", buf);
         }
     }
-    if (tile >= 312 && tile <= 320) {
+    if (tile >= 309 && tile <= 320) {
         // 16x16x32 MFMA, (16 * (tile - 300)) x 256 tile: bf16, plain GEMM (no convolution, no second segment)
-        VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 / 312..320 are bf16, single-source");
+        VLMO_CHECK_ARG(dtype == VLMO_BF16 && !gp.g[0].k1, "vlmo_gemm_nt: tiles 106..110 / 309..320 are bf16, single-source");
         ProfScope prof(80 + epi, 2.0 * Mtot * N * K, stream);
         switch (tile) {
+            case 309: return launch_nt16<bf16, 9>(epi, gp, stream);
+            case 310: return launch_nt16<bf16, 10>(epi, gp, stream);
+            case 311: return launch_nt16<bf16, 11>(epi, gp, stream);
             case 312: return launch_nt16<bf16, 12>(epi, gp, stream);
             case 313: return launch_nt16<bf16, 13>(epi, gp, stream);
             case 314: return launch_nt16<bf16, 14>(epi, gp, stream);
@@ -1936,7 +1949,7 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
         return tile == 908 ? launch_nt16<bf16, 16, 8, 1u>(epi, gp, stream) : launch_nt16<bf16, 16, 9, 1u>(epi, gp, stream);
     }
     if (tile == 208) return launch_nt16<bf16, 16, 0, 1u>(epi, gp, stream);     // measurement aid: schedule 0 (DMA issued in the MFMA segment), bias epilogue
-    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4, 8, 106..110 or 312..320 (got %d)", tile);
+    VLMO_CHECK_ARG(tile == 0 || tile == 3 || tile == 4 || tile == 8, "vlmo_gemm_nt: tile must be -1, 0, 3, 4, 8, 106..110 or 309..320 (got %d)", tile);
     if (tile == 4 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU))) tile = 0;
     if (tile == 8 && !(dtype == VLMO_BF16 && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_RESID || epi == EPI_DGELU))) tile = 3;
     ProfScope prof(epi + (tile == 3 || tile == 8 ? 16 : (tile == 4 ? 48 : 0)), 2.0 * Mtot * N * K, stream);

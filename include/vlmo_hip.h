@@ -86,7 +86,7 @@ int vlmo_abi_version(void);
  * 4 = 256x128x32 (two per CU; bf16 with the bias / bias+GELU epilogues, else it falls back to 0),
  * 8 = 192x256x64 ping-pong (bf16 with the bias / bias+GELU / residual / GELU-derivative epilogues, else 3): picked when its tile count
  * needs fewer dispatch rounds than 256x256 (VLMo-Large at 32 pairs per GPU),
- * 312..320 = (16 * (tile - 300)) x 256 x 64 ping-pong on v_mfma_f32_16x16x32 (192 .. 320 rows in 16-row steps; bf16, the
+ * 309..320 = (16 * (tile - 300)) x 256 x 64 ping-pong on v_mfma_f32_16x16x32 (144 .. 320 rows in 16-row steps; bf16, the
  * same four epilogues; 106..110 = the even heights 32 * (tile - 100)): tile height chosen per (M, N) so that the tiles
  * fill whole dispatch rounds of 256 CUs.
  * Replaces nn.functional.linear at vlmo.py:76-78 (qkv), vlmo.py:96 (proj), timm

@@ -65,10 +65,10 @@ def test_gemm_nt_bias_bf16_and_padding_rows(tile):
     _close(out2, ref.relu(), 1 / 128, 1e-2, 'bias+relu epilogue')
 
 
-@pytest.mark.parametrize('tile', [4, 8, 106, 110, 312, 313, 315, 317, 319, 320])
+@pytest.mark.parametrize('tile', [4, 8, 106, 110, 309, 310, 311, 312, 313, 315, 317, 319, 320])
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 768), (4099, 2304, 768), (77, 128, 192)])
 def test_gemm_nt_tile4_small_integers(tile, M, N, K):
-    """The 256x128x32 and 192x256x64 tiles and the 16x16x32-MFMA tiles 312..320 ((16 * (tile - 300)) x 256, odd heights = wave groups of different size; 106..110 = 32 * (tile - 100) rows: a new fragment
+    """The 256x128x32 and 192x256x64 tiles and the 16x16x32-MFMA tiles 309..320 ((16 * (tile - 300)) x 256, odd heights = wave groups of different size; 106..110 = 32 * (tile - 100) rows: a new fragment
     layout, a new accumulator -> LDS map, staging with a ragged last instruction at 224 / 288 rows) exist for a few
     epilogues only (bf16 output): integer operands small enough
     that every output is an integer below 256 in magnitude, i.e. exact in bf16 -- a fragment-layout or swizzle error of
@@ -166,7 +166,7 @@ def test_gemm_nt_dgelu_column_partials(M):
     want = (A.float() @ B.float().t()) * a.grad
     nblk = (M + 15) // 16
     ref16 = torch.stack([want[16 * b:16 * b + 16].sum(0) for b in range(nblk)])
-    for tile in (0, 3, 8, 106, 312, 313, 315, 316, 317, 319, 320):
+    for tile in (0, 3, 8, 106, 309, 310, 311, 312, 313, 315, 316, 317, 319, 320):
         cp = torch.full((nblk + 1, N), float('nan'), device=DEV)
         dg2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         hip.gemm_nt(hip.EPI_DGELU, A, B, M, N, K, dg2, aux=aux, colpart=cp, tile=tile)

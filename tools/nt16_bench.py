@@ -16,6 +16,7 @@ ap.add_argument('--reps', type=int, default=25)
 ap.add_argument('--shapes', default='')
 ap.add_argument('--drop', type=float, default=0.1)
 ap.add_argument('--tiles', default='', help='override the candidate list, e.g. 107,207')
+ap.add_argument('--d', type=int, default=768, help='model width (N and K of the shapes scale with it)')
 args = ap.parse_args()
 dev, M = 'cuda', args.M
 
@@ -29,6 +30,8 @@ SHAPES = {                      # name: (epilogue, N, K, candidate tiles)
     'dgrad_qkv': (hip.EPI_BIAS, 768, 2304, [314, 313, 3]),
     'dgrad_proj': (hip.EPI_BIAS, 768, 768, [314, 313, 3]),
 }
+if args.d != 768:               # another width (VLMo-Large: --d 1024 --M 8352): same GEMMs, N / K scaled
+    SHAPES = {k: (e, N * args.d // 768, K * args.d // 768, t) for k, (e, N, K, t) in SHAPES.items()}
 names = [n for n in args.shapes.split(',') if n] or list(SHAPES)
 drop = hip.drop_params(args.drop, True)
 

@@ -29,7 +29,7 @@ for tile in [int(t) for t in os.environ.get('PROBE_TILES', '3,0').split(',')]:
         A = torch.randn(M, K, device=dev).bfloat16()
         B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         t = timeit(lambda: hip.gemm_nt(hip.EPI_BIAS, A, B, M, N, K, out, bias=bias, tile=tile))
-        bm = 16 * (tile - 300) if tile >= 312 else (128 if tile == 0 else 256)       # 312..320: the 16x16x32 kernels
+        bm = 16 * (tile - 300) if tile >= 309 else (128 if tile == 0 else 256)       # 309..320: the 16x16x32 kernels
         bn = 128 if tile == 0 else 256
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         slots = 512 if tile == 0 else 256
