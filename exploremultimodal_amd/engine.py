@@ -510,7 +510,26 @@ class BlockFn(torch.autograd.Function):
         return (dx0, None, *grads)
 
 
-WGRAD_BATCH = int(_os.environ.get('VLMO_WGRAD_BATCH', '2'))     # blocks per deferred weight-gradient launch
+WGRAD_BATCH = int(_os.environ.get('VLMO_WGRAD_BATCH', '2'))     # blocks per deferred weight-gradient launch; 0 = by tile count
+
+
+def wgrad_batch_for(d, hid, cus=256, max_batch=4):
+    """Blocks per batched weight-gradient launch.  Default: 2 (VLMo-Base: 108 output tiles of 256 x 256 per block -> 216 =
+    one dispatch round).  VLMO_WGRAD_BATCH=0 picks the count whose tiles fill whole rounds (VLMo-Large: 192 per block -> 4
+    blocks = 768 = exactly three rounds, where 2 blocks take two rounds for 1.5): measured, the side stream's rounds are not
+    what the step waits for -- Large, 32 pairs, one box: (batch, temporary sets) = (2, 4) 24.80 ms, (4, 5) 25.35, (4, 6)
+    24.91, (4, 8) 24.92, (2, 6) 24.85; Base (2, 4) 14.38, (4, 6) 14.48 -- the CUs a partial round leaves idle are taken by the
+    main stream's kernels, and a batch of four holds its blocks' temporaries longer."""
+    if WGRAD_BATCH > 0:
+        return WGRAD_BATCH
+    c = lambda n: -(-n // 256)
+    tiles = c(d) * c(3 * d) + c(d) * c(d) + 2 * c(d) * c(hid)
+    best, best_cost = 1, None
+    for b in range(1, max_batch + 1):
+        cost = -(-b * tiles // cus) / b
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = b, cost
+    return best
 TMP_SETS = int(_os.environ.get('VLMO_TMP_SETS', '4'))            # rotation depth of the backward temporaries
 USE_STACK = _os.environ.get('VLMO_STACK', '1') != '0'            # one native call per pass (else one per block)
 WGRAD_STORE = _os.environ.get('VLMO_WGRAD_STORE', '1') != '0'    # weight-gradient matrices written, not zero-filled + accumulated
@@ -700,8 +719,9 @@ class StackFn(torch.autograd.Function):
         sink = ctx.sink
         shared_n = 6 * d + 3 * d * d + d * d + d + 3 * d
         exp_n = 2 * hid * d + hid + d
-        nsets = max(1, min(TMP_SETS, nb))
-        batch = max(1, min(WGRAD_BATCH, nsets - 1)) if nb > nsets else max(1, WGRAD_BATCH)
+        want = wgrad_batch_for(d, hid)
+        nsets = max(1, min(max(TMP_SETS, want + 1), nb))
+        batch = max(1, min(want, nsets - 1)) if nb > nsets else max(1, want)
         # persistent scratch: backward temporaries (dz2 | du(4) | dy2=dctx | dz1 | dqkv(3) | dy1 bf16) and column
         # workspaces, one set per block in flight; dx1 and the dx ping-pong
         tb = _persist(dev, 'tb', nsets * 11 * md, torch.bfloat16)
