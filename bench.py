@@ -266,6 +266,9 @@ def main():
 
     B = args.batch
     batch = synth.synth_batch(mc, B, seed=1234 + rank, mim=args.objective == 'full')
+    if args.objective == 'full':        # what the input hand-off (prefetch.DataLoaderX) attaches to every batch on the host
+        from exploremultimodal_amd.objectives import attach_row_indices
+        attach_row_indices(batch)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
     P = synth.num_img_tokens(mc)
     img = batch['image'].to(dev)

@@ -45,13 +45,42 @@ class GatherLayer(torch.autograd.Function):
         return grad_input[ctx.rank * bs:(ctx.rank + 1) * bs], None, None
 
 
-def compute_accuracy(logits, target):
-    """objectives.py:24-37 -> (mean accuracy over labels != -100, their count)."""
+def compute_accuracy(logits, target, all_valid=False):
+    """objectives.py:24-37 -> (mean accuracy over labels != -100, their count).  ``all_valid``: the caller built the
+    targets itself and none is -100 (ITC: arange, ITM: ones / zeros) -- same values without the three host
+    synchronisations of the masked form (``int(keep.sum())`` and two boolean gathers)."""
+    if all_valid:
+        n = target.numel()
+        if n == 0:
+            return torch.tensor(0, device=target.device), 0
+        return (logits.argmax(dim=-1) == target).float().mean(), n
     keep = target != -100
     n = int(keep.sum())
     if n == 0:
         return torch.tensor(0, device=target.device), 0
     return (logits.argmax(dim=-1)[keep] == target[keep]).float().mean(), n
+
+
+def attach_row_indices(batch):
+    """Input hand-off companion: on the HOST copy of a batch, before its upload, list the rows the two
+    vocabulary heads will gather -- ``_mlm_rows`` = flat indices into [B * T] of the positions whose MLM label is not -100
+    (objectives.py:52-56), ``_mim_rows`` = flat indices into [B * patches] of the masked patches and ``_mim_tok_rows`` = the
+    same positions in the [B * (patches + 1)] token rows (CLS first) (objectives.py:542-570).  With them compute_mlm /
+    compute_mim gather by index (``index_select``: the row count is known on the host) instead of by boolean mask, which
+    has to ask the device for its count: four host synchronisations per step, two more in the backward.  Same rows, same
+    order (ascending) as the boolean form.  A batch without these keys takes the reference's boolean path.  The keys
+    describe THIS batch's masks: whoever edits ``text_labels_mlm`` / ``image_bool_masked_pos`` afterwards drops them."""
+    lab = batch.get('text_labels_mlm')
+    if torch.is_tensor(lab) and not lab.is_cuda:
+        batch['_mlm_rows'] = (lab.reshape(-1) != -100).nonzero(as_tuple=False).reshape(-1)
+    bm = batch.get('image_bool_masked_pos')
+    if torch.is_tensor(bm) and not bm.is_cuda:
+        flat = bm.reshape(bm.shape[0], -1) != 0
+        rows = flat.reshape(-1).nonzero(as_tuple=False).reshape(-1)
+        patches = flat.shape[1]
+        batch['_mim_rows'] = rows
+        batch['_mim_tok_rows'] = rows + torch.div(rows, patches, rounding_mode='floor') + 1
+    return batch
 
 
 def _vocab_head_loss(model, head, feats, labels, vocab):
@@ -90,9 +119,15 @@ def compute_mlm(model, batch):
         mode = 'img-txt' if any('image' in k for k in batch.keys()) else 'txt_only'
         infer = model.infer(batch, infer_mode=mode, mask_txt=True, mask_img=False)
     labels_all = infer['txt_labels']
-    picked = labels_all != -100
-    feats = infer['txt_feats'][picked].contiguous()          # [n_masked, d]
-    labels = labels_all[picked]
+    rows = batch.get('_mlm_rows')
+    if rows is not None and rows.device == labels_all.device:
+        tf = infer['txt_feats']
+        feats = tf.reshape(-1, tf.shape[-1]).index_select(0, rows)      # [n_masked, d], no host synchronisation
+        labels = labels_all.reshape(-1).index_select(0, rows)
+    else:
+        picked = labels_all != -100
+        feats = infer['txt_feats'][picked].contiguous()          # [n_masked, d]
+        labels = labels_all[picked]
     loss, logits, acc, cnt = _vocab_head_loss(model, model.mlm_head, feats, labels, model.config.model.vocab_size)
     return {'mlm_task_loss': loss, 'mlm_logits': logits, 'mlm_labels': labels, 'mlm_ids': infer['txt_ids'],
             'mlm_mean_acc': acc, 'mlm_count': cnt}
@@ -128,8 +163,8 @@ def compute_itc(model, batch):
         sim_t2i = sim_i2t.t()
     i2t_loss = F.cross_entropy(sim_i2t, sim_targets)
     t2i_loss = F.cross_entropy(sim_t2i, sim_targets)
-    itc_i2t_mean_acc, itc_i2t_count = compute_accuracy(sim_i2t[:, :bs], sim_targets)
-    itc_t2i_mean_acc, itc_t2i_count = compute_accuracy(sim_t2i[:, :bs], sim_targets)
+    itc_i2t_mean_acc, itc_i2t_count = compute_accuracy(sim_i2t[:, :bs], sim_targets, all_valid=True)
+    itc_t2i_mean_acc, itc_t2i_count = compute_accuracy(sim_t2i[:, :bs], sim_targets, all_valid=True)
     return {'itc_task_loss': (i2t_loss + t2i_loss) / 2, 'i2t_Loss': i2t_loss, 't2i_Loss': t2i_loss,
             'sim_i2t': sim_i2t, 'sim_t2i': sim_t2i, 'itc_temp': temp.data,
             'itc_i2t_mean_acc': itc_i2t_mean_acc, 'itc_i2t_count': itc_i2t_count,
@@ -179,7 +214,7 @@ def compute_itm(model, batch, sim_dict=None):
     itm_labels = torch.cat([torch.ones(1 * bs, dtype=torch.long, device=itm_logits.device),
                             torch.zeros(2 * bs, dtype=torch.long, device=itm_logits.device)], dim=0)
     itm_loss = F.cross_entropy(itm_logits, itm_labels)
-    itm_mean_acc, itm_count = compute_accuracy(itm_logits, itm_labels)
+    itm_mean_acc, itm_count = compute_accuracy(itm_logits, itm_labels, all_valid=True)
     return {'itm_task_loss': itm_loss, 'itm_logits': itm_logits, 'itm_labels': itm_labels,
             'itm_mean_acc': itm_mean_acc, 'itm_count': itm_count}
 
@@ -190,7 +225,9 @@ def compute_mim(module, batch):
         input_ids = module.d_vae.get_codebook_indices(batch['image4dalle']).flatten(1)
         batch['image_bool_masked_pos'] = batch['image_bool_masked_pos'].flatten(1).to(torch.bool)
         bool_masked_pos = batch['image_bool_masked_pos']
-        mim_labels = input_ids[bool_masked_pos]
+        rows, tok_rows = batch.get('_mim_rows'), batch.get('_mim_tok_rows')
+        by_index = rows is not None and tok_rows is not None and rows.device == input_ids.device
+        mim_labels = input_ids.reshape(-1).index_select(0, rows) if by_index else input_ids[bool_masked_pos]
     pos = module.config.train.mim_head_pos
     if batch.get('_mim_infer') is not None:
         infer = batch['_mim_infer']
@@ -205,7 +242,11 @@ def compute_mim(module, batch):
         infer = {'img_feats': img_feats}
     else:
         raise KeyError(f'unknown mim_head_pos {pos!r}')
-    feats = infer['img_feats'][:, 1:][bool_masked_pos].contiguous()      # [n_masked, d] (patch tokens only)
+    if by_index and infer['img_feats'].shape[1] == bool_masked_pos.shape[1] + 1:
+        xf = infer['img_feats']
+        feats = xf.reshape(-1, xf.shape[-1]).index_select(0, tok_rows)       # the same rows, CLS skipped by the index
+    else:
+        feats = infer['img_feats'][:, 1:][bool_masked_pos].contiguous()      # [n_masked, d] (patch tokens only)
     loss, logits, acc, cnt = _vocab_head_loss(module, module.mim_head, feats, mim_labels,
                                               module.config.model.img_vocab_size)
     return {'mim_task_loss': loss, 'mim_logits': logits, 'mim_labels': mim_labels, 'mim_mean_acc': acc,

@@ -114,6 +114,10 @@ class DataLoaderX(DataLoader):
     def preload(self):
         """Pull the next batch from the producer and start its upload on the copy stream."""
         self.batch = next(self.iter, None)
+        if isinstance(self.batch, dict):
+            # rows the MLM / MIM heads will gather, listed while the masks are still host tensors (objectives.attach_row_indices)
+            from .objectives import attach_row_indices
+            attach_row_indices(self.batch)
         if self.batch is not None and self._gpu:
             with torch.cuda.stream(self.stream):
                 self.batch = _walk(self.batch, self._to_device)

@@ -185,6 +185,51 @@ def test_merged_passes_equal_pass_by_pass(golden_dir):
         assert (g0[k] - g1[k]).norm().item() / denom <= 2e-2, (k, (g0[k] - g1[k]).norm().item() / denom)
 
 
+@pytest.mark.parametrize('merged', [False, True])
+def test_row_indices_from_the_host_equal_the_boolean_gathers(golden_dir, merged):
+    """objectives.attach_row_indices (what prefetch.DataLoaderX adds to a batch before its upload): the MLM / MIM heads
+    gather by index instead of by boolean mask -- identical outputs, counts and gradients, and no host synchronisation
+    left in the forward of the four objectives (torch.cuda.set_sync_debug_mode('error'))."""
+    from exploremultimodal_amd.objectives import attach_row_indices
+    g = np.load(os.path.join(golden_dir, 'module_mini.npz'))
+    B = int(g['meta.B'])
+    outs = []
+    for indexed in (False, True):
+        model, cfg = _build()
+        cfg.train.merge_passes = merged
+        host = synth.synth_batch(cfg.model, B, seed=1234)
+        if indexed:
+            attach_row_indices(host)
+            lab = host['text_labels_mlm']
+            assert torch.equal(host['_mlm_rows'], (lab.reshape(-1) != -100).nonzero().reshape(-1))
+            bm = host['image_bool_masked_pos'].reshape(B, -1) != 0
+            assert torch.equal(host['_mim_rows'], bm.reshape(-1).nonzero().reshape(-1))
+            full = torch.cat([torch.zeros(B, 1, dtype=torch.bool), bm], 1)          # CLS token first
+            assert torch.equal(host['_mim_tok_rows'], full.reshape(-1).nonzero().reshape(-1))
+        batch = {k: v.to(DEV) for k, v in host.items()}
+        batch['itm_neg_idx'] = (torch.from_numpy(g['itm_img_neg_idx']).to(DEV), torch.from_numpy(g['itm_txt_neg_idx']).to(DEV))
+        if indexed:
+            model(dict(batch))                 # first call: allocations, weight shadows
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode('error')
+        try:
+            ret = model(dict(batch))
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        total = sum(v for k, v in ret.items() if 'task_loss' in k)
+        total.backward()
+        outs.append((ret, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (r0, g0), (r1, g1) = outs
+    assert set(r0) == set(r1)
+    for k in r0:
+        if torch.is_tensor(r0[k]):
+            assert torch.equal(r0[k].detach(), r1[k].detach()), k
+        else:
+            assert r0[k] == r1[k], k
+    for k in g0:
+        assert (g0[k] - g1[k]).norm().item() <= 1e-3 * (g0[k].norm().item() + 1e-12), k
+
+
 def test_itc_global_reduce_branch_single_rank():
     """compute_itc with config.train.global_reduce (GatherLayer over RCCL, objectives.py:99-108) at world size 1 equals
     the in-batch branch: same similarities, loss and feature gradients."""

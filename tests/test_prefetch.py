@@ -61,3 +61,33 @@ def test_dataloaderx_uploads_on_a_side_stream():
     it = iter(dl)
     next(it)
     dl.shutdown()                              # stops the thread mid-epoch
+
+
+def test_dataloaderx_attaches_the_head_row_indices():
+    """The hand-off lists, on the host, the rows the MLM / MIM heads gather (objectives.attach_row_indices)."""
+    from exploremultimodal_amd.prefetch import DataLoaderX
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(i)
+            lab = torch.full((8,), -100, dtype=torch.int64)
+            lab[torch.randperm(8, generator=g)[:2]] = 7
+            bm = torch.zeros(2, 2, dtype=torch.int64)
+            bm.view(-1)[i % 4] = 1
+            return {'text_labels_mlm': lab, 'image_bool_masked_pos': bm, 'x': torch.zeros(3)}
+
+    dl = DataLoaderX(None, batch_size=2, dataset=DS(), shuffle=False)
+    seen = 0
+    for b in dl:
+        lab, bm = b['text_labels_mlm'], b['image_bool_masked_pos']
+        assert torch.equal(b['_mlm_rows'], (lab.reshape(-1) != -100).nonzero().reshape(-1))
+        flat = bm.reshape(bm.shape[0], -1) != 0
+        assert torch.equal(b['_mim_rows'], flat.reshape(-1).nonzero().reshape(-1))
+        full = torch.cat([torch.zeros(flat.shape[0], 1, dtype=torch.bool), flat], 1)
+        assert torch.equal(b['_mim_tok_rows'], full.reshape(-1).nonzero().reshape(-1))
+        seen += 1
+    assert seen == 2
+    dl.shutdown()
