@@ -360,6 +360,28 @@ def main():
             step()
         comm_ms_per_step = round(reducer.comm_ms() / 3, 4)
         reducer.timing = False
+    if os.environ.get('VLMO_SYNC_PROBE'):
+        # measurement aid: the host <-> device synchronisation points of one step, innermost frame inside this repository
+        import collections
+        import traceback
+        import warnings
+        sites, root = collections.Counter(), os.path.dirname(os.path.abspath(__file__))
+
+        def _show(message, category, filename, lineno, file=None, line=None):
+            if 'synchronizing' in str(message) and 'prototype feature' not in str(message):
+                where = [f'{os.path.relpath(fr.filename, root)}:{fr.lineno} {fr.line}' for fr in traceback.extract_stack()[:-1]
+                         if fr.filename.startswith(root)]
+                sites[where[-1] if where else f'{filename}:{lineno}'] += 1
+        old_show, warnings.showwarning = warnings.showwarning, _show
+        warnings.simplefilter('always')
+        torch.cuda.set_sync_debug_mode('warn')
+        step()
+        torch.cuda.set_sync_debug_mode('default')
+        warnings.showwarning = old_show
+        torch.cuda.synchronize()
+        for k, v in sites.most_common():
+            log(f'sync probe: {v:3d} x {k}')
+        log(f'sync probe: {sum(sites.values())} synchronisation(s) in one step')
     log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue with an empty queue {host_ms:.2f} ms/step; '
         f'{t_issue / args.steps * 1e3:.2f} ms/step while the queue is full)')
     if rank == 0:

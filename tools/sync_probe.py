@@ -45,7 +45,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def showwarning(message, category, filename, lineno, file=None, line=None):
-    if 'synchroniz' not in str(message):
+    if 'synchronizing' not in str(message) or 'prototype feature' in str(message):
         return
     where = None
     for fr in traceback.extract_stack()[:-1]:
