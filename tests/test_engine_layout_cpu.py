@@ -37,3 +37,12 @@ def test_bucket_layouts_match_the_carved_gradients():
     assert lay[id(shared[6])] - lay[id(shared[5])] == 2 * d
     covered = sum(p.numel() for p in shared)
     assert shared_n - covered == d
+
+
+def test_wgrad_batch_by_tile_count(monkeypatch):
+    """engine.wgrad_batch_for: default two blocks per launch; VLMO_WGRAD_BATCH=0 = the count whose tiles fill whole rounds."""
+    from exploremultimodal_amd import engine
+    assert engine.wgrad_batch_for(768, 3072) == engine.WGRAD_BATCH == 2
+    monkeypatch.setattr(engine, 'WGRAD_BATCH', 0)
+    assert engine.wgrad_batch_for(768, 3072) == 2        # 108 tiles per block: 216 = one round of 256 CUs
+    assert engine.wgrad_batch_for(1024, 4096) == 4       # 192 per block: 768 = exactly three rounds
