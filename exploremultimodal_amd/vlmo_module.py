@@ -8,6 +8,8 @@ from collections import defaultdict
 from functools import partial
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -209,11 +211,39 @@ class VlmoModule(nn.Module):
         if 'mim' in names:
             with torch.no_grad():
                 batch['image_bool_masked_pos'] = batch['image_bool_masked_pos'].flatten(1).to(torch.bool)
+        # ---- V and L passes as ONE pass of unfused (image, text) pairs: forward_features with fusion_layer = depth runs the
+        # image tokens through the 'v' experts and the text tokens through the 'l' experts of EVERY block and never joins them
+        # (vlmo.py:400-413 with an empty 'vl' range), i.e. exactly the image-only and text-only passes side by side.  The
+        # text-only pass of B sequences alone is ~300 launches of 2 048-row kernels; riding with the 2B images it costs its rows.
+        # Pairs: (ITC image_i, text_i), (MIM masked image_i, text_i again -- its text half is discarded, no gradient enters it).
+        unfused = ('itc' in names and 'mim' in names and self.transformer_m is None
+                   and getattr(self.config.train, 'merge_unfused', os.environ.get('VLMO_MERGE_UNFUSED', '1') != '0'))
+        if unfused:
+            tr = self.transformer
+            T, depth = tr.max_text_len, len(tr.blocks)
+            bmp = batch['image_bool_masked_pos']
+            img2 = torch.cat([batch['image'], batch['image']], 0)
+            bmp2 = torch.cat([torch.zeros_like(bmp), bmp], 0)
+            ids2 = torch.cat([batch['text_ids'], batch['text_ids']], 0)
+            tm2 = torch.cat([batch['text_mask'], batch['text_mask']], 0)
+            ones = torch.ones([2 * B, tr.patch_embed.num_patches + 1], dtype=torch.int64, device=dev)
+            co, _ = tr.forward_features(img=img2, txt=ids2, img_attn_masks=ones, txt_attn_masks=tm2, bool_masked_pos=bmp2,
+                                        fusion_layer=depth)
+            img_itc, img_mim, txt_itc = co[:B, T:], co[B:, T:], co[:B, :T]
+            batch['_itc_img_infer'] = {'txt_feats': None, 'img_feats': img_itc, 'co_feats': img_itc, 'cls_feats': None,
+                                       'img_masks': ones[:B], 'img_bool_masked_pos': None, 'txt_labels': None,
+                                       'txt_ids': None, 'txt_masks': None}
+            batch['_mim_infer'] = {'txt_feats': None, 'img_feats': img_mim, 'co_feats': img_mim, 'cls_feats': None,
+                                   'img_masks': ones[B:], 'img_bool_masked_pos': bmp, 'txt_labels': None,
+                                   'txt_ids': None, 'txt_masks': None}
+            batch['_itc_txt_infer'] = {'txt_feats': txt_itc, 'img_feats': None, 'co_feats': txt_itc, 'cls_feats': None,
+                                       'img_masks': None, 'img_bool_masked_pos': None, 'txt_labels': None,
+                                       'txt_ids': batch['text_ids'], 'txt_masks': batch['text_mask']}
         # ---- V pass
         v_parts = []
-        if 'itc' in names:
+        if 'itc' in names and not unfused:
             v_parts.append('itc')
-        if 'mim' in names:
+        if 'mim' in names and not unfused:
             v_parts.append('mim')
         if v_parts:
             nb = len(v_parts)
@@ -231,7 +261,8 @@ class VlmoModule(nn.Module):
                     batch['_mim_infer'] = piece
         # ---- L pass, then ITC (its similarities drive the ITM hard negatives)
         if 'itc' in names:
-            batch['_itc_txt_infer'] = self.infer(batch, infer_mode='txt_only')
+            if not unfused:
+                batch['_itc_txt_infer'] = self.infer(batch, infer_mode='txt_only')
             ret.update(objectives.compute_itc(self, batch))
         # ---- VL pass
         vl_parts, ids, masks, imgs = [], [], [], []
