@@ -98,6 +98,21 @@ def test_dual_epilogue_maxpool_im2col_argmax():
     assert (logits.max(1).values - picked).max().item() < 1e-3
 
 
+@pytest.mark.parametrize('B,C,H,W,Kpad', [(2, 3, 112, 112, 192), (1, 3, 16, 224, 192), (3, 3, 8, 9, 192),
+                                           (1, 1, 8, 40, 64), (2, 5, 8, 8, 256)])
+def test_im2col_row_form_equals_unfold(B, C, H, W, Kpad):
+    """The stem's patch matrix (dall_e/encoder.py:75, utils.py:14 padding (kw-1)//2) from the LDS-staged row kernel:
+    every column of every pixel equal to F.unfold, padding columns zero; widths that are not multiples of the pixels
+    per pass, one and five input channels."""
+    g = torch.Generator().manual_seed(7)
+    img = (torch.rand(B, C, H, W, generator=g) - 0.3).to(DEV)
+    cols = torch.full((B * H * W, Kpad), float('nan'), device=DEV, dtype=torch.float16)
+    hip.dvae_im2col(img, cols, 7, Kpad)
+    refc = F.unfold(img, 7, padding=3).transpose(1, 2).reshape(-1, C * 49)
+    assert torch.equal(cols[:, :C * 49], refc.half())
+    assert (cols[:, C * 49:] == 0).all()
+
+
 def _encoder(**kw):
     from exploremultimodal_amd.dvae import Encoder
     enc = Encoder(**kw)
