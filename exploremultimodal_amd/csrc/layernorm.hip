@@ -5,6 +5,7 @@
 // registers for both the statistics and the normalisation.
 #include "common.h"
 #include "vlmo_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -99,7 +100,7 @@ struct ResidArgs {
     uint64_t seed1;
 };
 
-template <int VPL, bool DY_F32, bool RESID>
+template <int VPL, bool DY_F32, bool RESID, bool NTL = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const int32_t* __restrict__ rowmap,
                                                      const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -152,15 +153,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int j = 0; j < VPL; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
+                // NTL: every operand row is read exactly once by this kernel and by nobody after it -- streamed past the caches
+                auto ld = [](const auto* p) { return NTL ? __builtin_nontemporal_load(p) : *p; };
                 if constexpr (DY_F32) {
-                    r.dy[j] = ((const f32x4*)((const float*)dy + (size_t)sm * d))[i];
+                    r.dy[j] = ld((const f32x4*)((const float*)dy + (size_t)sm * d) + i);
                 } else {
-                    const bf16x4 t = ((const bf16x4*)((const bf16*)dy + (size_t)sm * d))[i];
+                    const bf16x4 t = ld((const bf16x4*)((const bf16*)dy + (size_t)sm * d) + i);
                     r.dy[j] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
                 }
-                r.x[j] = ((const f32x4*)(x + (size_t)m * d))[i];
-                r.dr[j] = dres ? ((const f32x4*)(dres + (size_t)m * d))[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (RESID) r.z[j] = ((const bf16x4*)(ra.zd + (size_t)m * d))[i];
+                r.x[j] = ld((const f32x4*)(x + (size_t)m * d) + i);
+                r.dr[j] = dres ? ld((const f32x4*)(dres + (size_t)m * d) + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (RESID) r.z[j] = ld((const bf16x4*)(ra.zd + (size_t)m * d) + i);
             }
         }
     };
@@ -292,8 +295,11 @@ int ln_bwd_launch(const void* dy, int dy_f32, const int32_t* rowmap, const float
         }
     }
     const ResidArgs none{};
+    static const bool ntl = getenv("VLMO_LN_BWD_NT") && atoi(getenv("VLMO_LN_BWD_NT")) != 0;     // measurement aid
 #define LNB(V)                                                                                         \
-    if (ra)                                                                                            \
+    if (ra && ntl)                                                                                     \
+        hipLaunchKernelGGL((ln_bwd_kernel<V, false, true, true>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb, *ra); \
+    else if (ra)                                                                                       \
         hipLaunchKernelGGL((ln_bwd_kernel<V, false, true>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb, *ra); \
     else if (dy_f32)                                                                                   \
         hipLaunchKernelGGL((ln_bwd_kernel<V, true, false>), dim3(grid), dim3(256), 0, stream, dy, rowmap, x, w, mean, rstd, dres, dx, ws, M, d, rpb, none); \

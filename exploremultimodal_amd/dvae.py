@@ -23,6 +23,8 @@ from . import hip
 
 logit_laplace_eps = 0.1
 OUTPUT_FP16_WEIGHTS = os.environ.get('VLMO_DVAE_OUTPUT_FP16', '0') == '1'
+# measurement switch: 0 = the output convolution as one launch whatever its last dispatch round looks like
+OUTPUT_ROW_SPLIT = os.environ.get('VLMO_DVAE_OUT_SPLIT', '1') != '0'
 
 
 def map_pixels(x):
@@ -209,6 +211,18 @@ class Encoder(nn.Module):
                 raw, rel, h, w, M = rp, None, h // 2, w // 2, Mp
         return rel, (B, h, w)
 
+    @staticmethod
+    def _row_parts(M, N):
+        """Row ranges [(r0, r1, tile)] of the output convolution.  Its 256 x 256 tiles run one per CU, so a last dispatch
+        round that is mostly empty costs a whole round (64 images of 112 x 112: 49 x 32 = 1 568 tiles = 6.125 rounds of 256
+        CUs, paid as 7): the rows of that round go out as a second launch of 128 x 128 tiles instead."""
+        nt, rt = -(-N // 256), -(-M // 256)
+        full, left = divmod(rt * nt, 256)
+        if not OUTPUT_ROW_SPLIT or full == 0 or left == 0 or left > 64:
+            return [(0, M, -1)]
+        r = (full * 256 // nt) * 256
+        return [(0, r, 3), (r, M, 0)] if 0 < r < M else [(0, M, -1)]
+
     def forward(self, x):
         """encoder.py:123-133 -> logits fp32 [B, vocab, H/8, W/8]."""
         rel, (B, h, w) = self._features(x)
@@ -216,7 +230,9 @@ class Encoder(nn.Module):
         M, C = rel.shape
         logits = torch.empty((M, self.vocab_size), dtype=torch.float32, device=x.device)
         # [x | x] against [w_hi | w_lo]: the activations are the second segment's source too (no doubled copy in HBM)
-        hip.gemm_nt(hip.EPI_F32, rel, wo, M, self.vocab_size, 2 * C, logits, bias=bo, A2=rel, k1=C)
+        for r0, r1, tile in self._row_parts(M, self.vocab_size):
+            hip.gemm_nt(hip.EPI_F32, rel[r0:r1], wo, r1 - r0, self.vocab_size, 2 * C, logits[r0:r1], bias=bo,
+                        A2=rel[r0:r1], k1=C, tile=tile)
         return logits.view(B, h, w, self.vocab_size).permute(0, 3, 1, 2)
 
     def codebook_indices(self, x):
@@ -232,7 +248,9 @@ class Encoder(nn.Module):
             hip.gemm_nt(hip.EPI_ARGMAX, rel, w16, M, self.vocab_size, C, part, bias=bo, ldo=nchunk)
         else:
             wo, bo = self.blocks.output.conv.shadow_split()
-            hip.gemm_nt(hip.EPI_ARGMAX, rel, wo, M, self.vocab_size, 2 * C, part, bias=bo, ldo=nchunk, A2=rel, k1=C)
+            for r0, r1, tile in self._row_parts(M, self.vocab_size):
+                hip.gemm_nt(hip.EPI_ARGMAX, rel[r0:r1], wo, r1 - r0, self.vocab_size, 2 * C, part[r0:r1], bias=bo,
+                            ldo=nchunk, A2=rel[r0:r1], k1=C, tile=tile)
         ids = torch.empty((M,), dtype=torch.int64, device=x.device)
         hip.argmax_reduce(part, nchunk, ids, M)
         return ids.view(B, h, w)
