@@ -42,6 +42,12 @@ struct AttnArgs {
     uint64_t seed;
     int bh0;             // dropout-mask index of the launch's first (sequence, head): a backward launch over a SUFFIX of the
                          // forward launch's sequences regenerates the forward's mask (vlmo.py:93 has one mask per call)
+    int warm;            // bwd: every workgroup touches the operand rows of the (sequence, head) `warm` workgroups further on (the
+                         // one its XCD sees a dispatch round later), one 4-byte load per 128-byte row piece; 0 = off
+    int split_tok;       // bwd, 0 = off: sequences longer than this many tokens (a multiple of 32) are differentiated by TWO
+                         // launches -- attn_bwd_kernel takes every tile pair that touches the last (fringe) tile and writes
+                         // partial dq / dk / dv rows, attn_bwd1_kernel then takes the pairs among the first split_tok tokens
+                         // and adds those partials (see vlmo_attn_bwd)
 };
 
 #define LOG2E 1.4426950408889634f
@@ -445,6 +451,40 @@ __device__ __forceinline__ void colsum_tiles(const f32x16* t, float w, float sca
         }
 }
 
+// The backward kernels run one workgroup per CU and stage ~165 KB per (sequence, head) before their first product; in a
+// training step those rows (the forward's qkv and ctx) come from HBM.  Their main loops issue no global loads at all, so
+// a workgroup uses the idle vector-memory path to pull the rows of a LATER workgroup of its own XCD (blockIdx % 8 picks
+// the XCD: + 256 = one dispatch round on) into that XCD's L2: token i of that item = thread i, one dword out of each
+// 128-byte row piece of q, k, v, dctx and ctx.  The values are folded into a word that is consumed after the loop (the
+// workgroup's last act is to retire them).
+// The loads are inline assembly into ONE register that stays live until warm_retire: written as C++ loads the compiler
+// folds the five values right behind the loads (one live register instead of five) and parks a full HBM round trip in
+// front of the main loop.  vmcnt retires in order, so the compiler's own counted waits only become stricter.
+__device__ __forceinline__ void warm_issue(const AttnArgs& a, int bh2, uint32_t& w) {
+    w = 0;
+    if (bh2 < (int)gridDim.x) {
+        const int sidx2 = bh2 / a.heads, hd2 = bh2 % a.heads;
+        const int rowA = a.seg[4 * sidx2 + 0], lenA = a.seg[4 * sidx2 + 1], rowB = a.seg[4 * sidx2 + 2], lenB = a.seg[4 * sidx2 + 3];
+        const int i = threadIdx.x;
+        if (i < lenA + lenB) {
+            const size_t row = (size_t)(i < lenA ? rowA + i : rowB + (i - lenA));
+            const bf16* q = a.qkv + row * 3 * a.d + hd2 * 64;
+            const bf16* k = q + a.d;
+            const bf16* v = k + a.d;
+            const bf16* g = a.dctx + row * a.d + hd2 * 64;
+            const bf16* o = a.ctx + row * a.d + hd2 * 64;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(q) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(k) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(v) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(g) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(o) : "memory");
+        }
+    }
+}
+__device__ __forceinline__ void warm_retire(uint32_t& w) {
+    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0" : "+v"(w)::"memory");
+}
+
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, const int NPAD) {
     const int IMG = NPAD * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -469,6 +509,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     if (threadIdx.x < 128) csum[threadIdx.x] = 0.f;
     __syncthreads();
     const int nq = (N + 31) >> 5;   // query tiles == key tiles (self-attention)
+    // fringe mode (a.split_tok): only the tile pairs with the LAST tile on either side; the rest is attn_bwd1_kernel's
+    const int ft = a.split_tok ? nq - 1 : -1;
+    if (a.split_tok && N <= a.split_tok) return;        // nothing beyond the single-pass kernel's reach (uniform exit)
     stage_image<8>(a.qkv, ld, hd * 64, rowidx, Qimg, nq * 4, wave, lane);
     stage_image<8>(a.qkv, ld, a.d + hd * 64, rowidx, Kimg, nq * 4, wave, lane);
     stage_image<8>(a.qkv, ld, 2 * a.d + hd * 64, rowidx, Vimg, nq * 4, wave, lane);
@@ -492,6 +535,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    uint32_t warm_word = 0;
+    if (a.warm) warm_issue(a, bh + a.warm, warm_word);
 
     const int l31 = lane & 31, h = lane >> 5;
     const uint32_t akey = att_key(a.seed, bh + a.bh0);
@@ -518,7 +563,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
     if (item >= 2 * nq) break;
     // ---- dQ item: dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
     if (item >= nq) {
-        const int qt = item - nq;
+        // fringe mode: the long item (the fringe query tile against every key tile) is handed out first
+        const int qt = ft < 0 ? item - nq : (item == nq ? ft : item - nq - 1);
+        const int kt0 = (ft < 0 || qt == ft) ? 0 : ft;
         const int qi = qt * 32 + l31;
         bf16x8 qf[4], df[4];
 #pragma unroll
@@ -529,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
         const float lq = lseq[qi], dl = delta[qi];
         const uint32_t rq = ((uint32_t)qi * 512u + 4u * h) * ATT_G + akey;
         f32x16 dQ[2] = {zero16(), zero16()};
-        for (int kt = 0; kt < nq; ++kt) {
+        for (int kt = kt0; kt < nq; ++kt) {
             {
                 f32x16 S = zero16(), dP = zero16();
 #pragma unroll
@@ -563,7 +610,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             }
         }
         if (a.qvsum) {
-            const float wq = qi < N ? 1.f : 0.f;
+            // (fringe mode: the partial rows enter the sums through the single-pass launch, which adds them to its tiles)
+            const float wq = (qi < N && (ft < 0 || qt == ft)) ? 1.f : 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -584,7 +632,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
 
     // ---- dK/dV item: dV^T[d][k] = sum_q dO^T[d][q] Pd[q][k] ; dK^T[d][k] = sum_q Q^T[d][q] dS[q][k]
     else {
-        const int kt = item;
+        const int kt = ft < 0 ? item : (item == 0 ? ft : item - 1);
+        const int qt0 = (ft < 0 || kt == ft) ? 0 : ft;
         const int ki = kt * 32 + l31;
         bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -597,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
         // compile-time constant adds
         const uint32_t rl = (uint32_t)ki * ATT_G + akey + (uint32_t)(4 * h) * ATT_G512;
         f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};
-        for (int qt = 0; qt < nq; ++qt) {
+        for (int qt = qt0; qt < nq; ++qt) {
             {
                 f32x16 S = zero16(), dP = zero16();
 #pragma unroll
@@ -639,7 +688,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
             }
         }
         if (a.qvsum) {
-            const float wk = ki < N ? 1.f : 0.f;
+            const float wk = (ki < N && (ft < 0 || kt == ft)) ? 1.f : 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -666,6 +715,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const AttnArgs a, cons
         if (threadIdx.x < 128)
             a.qvsum[(size_t)sidx * 2 * a.d + (threadIdx.x >> 6) * a.d + hd * 64 + (threadIdx.x & 63)] = csum[threadIdx.x];
     }
+    if (a.warm) warm_retire(warm_word);
 }
 
 // ------------------------------------------------------------------ backward, single pass
@@ -720,7 +770,9 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
     // delta, the log-sum-exp and this wave's V fragments are all issued together (a row table in LDS first costs two more
     // global round trips and a barrier: 6.4 of the 7.2 us a workgroup spent before its first product).
     const int rowA = a.seg[4 * sidx + 0], lenA = a.seg[4 * sidx + 1], rowB = a.seg[4 * sidx + 2], lenB = a.seg[4 * sidx + 3];
-    const int N = lenA + lenB;
+    // a.split_tok: the tokens beyond it (and their partial sums into the rows below it) were attn_bwd_kernel's
+    const bool add_partials = a.split_tok && lenA + lenB > a.split_tok;
+    const int N = add_partials ? a.split_tok : lenA + lenB;
     auto rowof = [&](int tok) {
         tok = min(tok, N - 1);
         return tok < lenA ? rowA + tok : rowB + (tok - lenA);
@@ -776,6 +828,8 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    uint32_t warm_word = 0;
+    if (a.warm) warm_issue(a, bh + a.warm, warm_word);
 
     const uint32_t akey = att_key(a.seed, bh + a.bh0);
     const float out_scale = a.scale * a.inv_keep;
@@ -975,6 +1029,25 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
     if (active && ki < N) {
         // ki doubles as the query index of the dQ tile this wave owns
         bf16* op = a.out + (size_t)krow * ld + hd * 64 + 4 * h;
+        if (add_partials) {
+            // the fringe launch left bf16 partial sums in these rows: added in fp32 in front of the one final rounding
+            // (in units of the accumulators, so that the stores below stay as they are)
+            const float iq = 1.f / out_scale, iv = keep_prob;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const bf16x4 pq = *(const bf16x4*)(op + dt * 32 + 8 * g4);
+                    const bf16x4 pk = *(const bf16x4*)(op + a.d + dt * 32 + 8 * g4);
+                    const bf16x4 pv = *(const bf16x4*)(op + 2 * a.d + dt * 32 + 8 * g4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dQ[dt][4 * g4 + e] = fmaf((float)pq[e], iq, dQ[dt][4 * g4 + e]);
+                        dK[dt][4 * g4 + e] = fmaf((float)pk[e], iq, dK[dt][4 * g4 + e]);
+                        dV[dt][4 * g4 + e] = fmaf((float)pv[e], iv, dV[dt][4 * g4 + e]);
+                    }
+                }
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -997,9 +1070,12 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const AttnArgs a, const 
             colsum_tiles(dV, wt, a.inv_keep, csum + 64, lane);
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 128; i += blockDim.x)
-            a.qvsum[(size_t)sidx * 2 * a.d + (i >> 6) * a.d + hd * 64 + (i & 63)] = csum[i];
+        for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+            float* dst = a.qvsum + (size_t)sidx * 2 * a.d + (i >> 6) * a.d + hd * 64 + (i & 63);
+            *dst = add_partials ? *dst + csum[i] : csum[i];     // the fringe launch left the fringe rows' sums there
+        }
     }
+    if (a.warm) warm_retire(warm_word);
 }
 
 // dynamic-LDS limit already raised for a kernel on a device (a process may drive several GPUs)
@@ -1128,9 +1204,27 @@ extern "C" int vlmo_attn_bwd(const void* qkv, const void* ctx, const void* dctx,
     a.inv_keep = drop_thresh ? inv_keep : 1.f;
     a.seed = seed;
     a.bh0 = mask_seq0 * heads;
+    static const int warm = getenv("VLMO_ATTN_WARM") ? atoi(getenv("VLMO_ATTN_WARM")) : 0;      // measurement aid
+    a.warm = warm;
     const int nt = (max_len + 31) / 32, nb = num_seq * heads;
     static const bool two_phase = getenv("VLMO_ATTN_BWD") && !strcmp(getenv("VLMO_ATTN_BWD"), "two_phase");   // measurement aid
-    if (two_phase || nt > 8)
+    static const bool split = getenv("VLMO_ATTN_BWD_SPLIT") && atoi(getenv("VLMO_ATTN_BWD_SPLIT")) != 0;       // measurement aid, off
+    if (!two_phase && split && nt == 9) {
+        // 257 .. 288 tokens (the fused layers at 64 text tokens: 261): one tile too many for the single-pass kernel's
+        // eight tile owners, and the two-phase kernel computes every S / dP tile twice.  The backward is a sum over
+        // (query tile, key tile) pairs whose terms only share the row constants lse and delta, so the 17 pairs that touch
+        // the ninth tile go to the two-phase kernel (two long items + sixteen one-step items; it writes the fringe rows
+        // and bf16 partial sums into the rows below) and the 64 pairs among the first 256 tokens to the single-pass
+        // kernel, which adds the partials in fp32 in front of its one rounding.  Exact (tests/test_kernels_gpu.py ran
+        // green on this path) and NOT the default: 91 + 36 us against 131 us back to back, but +0.34 ms per step
+        // (14.33 -> 14.67 ms, two in-session pairs) -- both launches stage every operand of a (sequence, head) through one
+        // CU, and in the step those operands are cold (tools/attn_cold_probe.py: +16 us per launch), so the prologue
+        // is paid twice.
+        a.split_tok = 256;
+        launch_bwd(a, nt, nb, stream);
+        VLMO_CHECK_LAUNCH("vlmo_attn_bwd(fringe)");
+        launch_bwd1(a, 8, nb, stream);
+    } else if (two_phase || nt > 8)
         launch_bwd(a, nt, nb, stream);
     else
         launch_bwd1(a, nt, nb, stream);

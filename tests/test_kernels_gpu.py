@@ -350,7 +350,8 @@ def _attn_ref(qkv, seg, keymask, heads, d, dctx=None, keep=None, inv_keep=1.0):
 
 
 @pytest.mark.parametrize('B,lenA,lenB,heads', [(3, 16, 17, 2), (2, 64, 0, 2), (2, 0, 197, 1),
-                                               (2, 64, 197, 2), (1, 40, 197, 3), (2, 24, 50, 4), (3, 16, 0, 2), (2, 0, 256, 1)])
+                                               (2, 64, 197, 2), (1, 40, 197, 3), (2, 24, 50, 4), (3, 16, 0, 2), (2, 0, 256, 1),
+                                               (2, 60, 197, 1), (1, 64, 224, 2), (2, 70, 200, 1)])
 def test_attention_fwd_bwd(B, lenA, lenB, heads):
     qkv, seg, keymask, M, d = _attn_case(B, lenA, lenB, heads, seed=B + lenA)
     N = lenA + lenB
@@ -395,6 +396,47 @@ def test_attention_mixed_lengths_in_one_launch():
         dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
         hip.attn_bwd(qkv, ctx, dctx, lse, seg, 2 * B, keymask, dqkv, heads, d, P, 64 ** -0.5, **kw)
         _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * ref_dqkv.abs().max().item(), 'attn dqkv (mixed)')
+
+
+def test_attention_backward_nine_tile_sequences_in_a_mixed_launch():
+    """One launch with sequences on both sides of the 256-token boundary between the single-pass and the two-phase
+    backward (257 .. 288 tokens take the latter; with VLMO_ATTN_BWD_SPLIT=1 two launches: the tile pairs that touch the
+    ninth tile in the two-phase kernel, the rest in the single-pass kernel, which adds the first launch's partial rows),
+    a packed two-range sequence, key masks that cover a whole fringe, dropout: dq / dk / dv of every row and the
+    per-sequence column sums against the fp32 reference with the replicated mask."""
+    heads = 2
+    d = heads * 64
+    lens = [270, 200, 257, 64, 288, 256]
+    starts = np.cumsum([0] + lens[:-1]).tolist()
+    M = sum(lens)
+    qkv = _rand(M, 3 * d, seed=11, scale=1.0)
+    # the 270-token sequence is packed from two row ranges like a fused text + image sequence
+    seg = [[s, n, 0, 0] for s, n in zip(starts, lens)]
+    seg[0] = [starts[0], 70, starts[0] + 70, 200]
+    seg = torch.tensor(seg, dtype=torch.int32).to(DEV)
+    keymask = torch.ones(M, dtype=torch.int32)
+    keymask[starts[0] + 40:starts[0] + 70] = 0
+    keymask[starts[2] + 250:starts[2] + 257] = 0          # the whole fringe of the 257-token sequence and a few more
+    keymask = keymask.to(DEV)
+    nseq, N = len(lens), max(lens)
+    for drop, seed in ((None, 0), (hip.drop_params(0.1, True), 0xABCDEF0123)):
+        kw = dict(drop=drop, seed=seed) if drop else {}
+        ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros(nseq * heads, 288, device=DEV)
+        hip.attn_fwd(qkv, seg, nseq, keymask, ctx, lse, heads, d, N, 64 ** -0.5, **kw)
+        keep = _attn_keep_mask(seed, nseq, heads, N, drop[0]) if drop else None
+        dctx = _rand(M, d, seed=80)
+        ref_ctx, ref_dqkv = _attn_ref(qkv, seg, keymask, heads, d, dctx, keep=keep, inv_keep=drop[1] if drop else 1.0)
+        _close(ctx, ref_ctx, 1 / 64, 1e-2, 'attn ctx (split launch)')
+        dqkv = torch.full((M, 3 * d), float('nan'), device=DEV, dtype=torch.bfloat16)
+        qv = torch.full((nseq, 2 * d), float('nan'), device=DEV)
+        hip.attn_bwd(qkv, ctx, dctx, lse, seg, nseq, keymask, dqkv, heads, d, N, 64 ** -0.5, qv_colsum=qv, **kw)
+        scale = ref_dqkv.abs().max().item()
+        _close(dqkv, ref_dqkv, 1 / 32, 2e-2 * scale, 'attn dqkv (split launch)')
+        for si, sg in enumerate(seg.tolist()):
+            rows = torch.cat([torch.arange(sg[0], sg[0] + sg[1]), torch.arange(sg[2], sg[2] + sg[3])]).to(DEV)
+            want = torch.cat([ref_dqkv[rows, :d].sum(0), ref_dqkv[rows, 2 * d:].sum(0)])
+            _close(qv[si], want, 1 / 32, 2e-2 * scale * len(rows) ** 0.5, f'attn qv column sums (split launch, sequence {si})')
 
 
 @pytest.mark.parametrize('B,lenA,lenB,heads', [(2, 64, 197, 2), (3, 16, 17, 1)])
