@@ -481,6 +481,9 @@ def main():
                                        'hbm_frac': round(pmc['step'].get('hbm_gbs', 0) / PEAK_HBM_GBS, 4),
                                        'mfma_busy': pmc['step'].get('mfma_busy')}
         out['host_enqueue_ms'] = round(host_ms, 3)
+        # which stream the weight gradients of the VL pass ran on (engine._use_side_stream: forced by VLMO_OVERLAP_WGRAD,
+        # else the side stream under a reducer or for passes of fewer than engine.ONE_STREAM_ROWS rows)
+        out['wgrad_stream'] = 'side' if engine._use_side_stream(engine.GRAD_SINK, B * (mc.max_text_len + P)) else 'main'
         if reducer is not None:
             # what a scaling run needs to check the exchange: communicator size as the communicator reports it, the
             # form chosen at start-up (GradReducer.autotune), bytes per step, time of the communication stream per step

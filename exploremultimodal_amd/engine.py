@@ -21,7 +21,25 @@ from . import hip
 LN_EPS = 1e-12          # vlmo_module.py:21-23
 GRAD_SINK = None         # set by dp.GradReducer: block gradients are accumulated straight into its flat buckets
 import os as _os
-OVERLAP_WGRAD = _os.environ.get('VLMO_OVERLAP_WGRAD', '1') != '0'   # weight-gradient GEMMs + bias column sums on a side stream
+# Weight-gradient GEMMs + bias column sums on a side stream: '1' always, '0' never, unset = by the rule below.
+# The GEMM kernels take whole CUs (128 KB of LDS, every vector register), so two streams time-slice the chip instead of
+# sharing it: the overlap pays only where the main stream's kernels leave CUs idle (short kernels, partial dispatch
+# rounds).  In-session A/Bs, side stream against one stream, no reducer: VLMo-Base at 64 pairs (16 704 rows per pass)
+# 14.70 / 14.66 / 14.66 against 14.63 / 14.64 / 14.64 ms and 14.25 / 14.25 against 14.18 / 14.20 on another box; the
+# four-loss objective at 32 pairs (passes of 33 408 and 12 608 rows) 48.1 / 47.9 against 47.3 / 47.3; VLMo-Large at 32
+# pairs (8 352 rows) 25.02 / 25.03 against 25.58 / 25.55.  So: one stream for passes of ONE_STREAM_ROWS rows and more, the
+# side stream below -- and always under a gradient reducer, where the side stream is what lets a block's gradients
+# finish (and their collective start) while the activation gradients of the blocks below are still being computed
+# (dp.GradReducer waits on the per-block grad_ready events).
+_ov = _os.environ.get('VLMO_OVERLAP_WGRAD')
+OVERLAP_WGRAD = None if _ov is None else _ov != '0'
+ONE_STREAM_ROWS = 12288
+
+
+def _use_side_stream(sink, rows):
+    if OVERLAP_WGRAD is not None:
+        return OVERLAP_WGRAD
+    return sink is not None or rows < ONE_STREAM_ROWS
 SIDE_MODE = _os.environ.get('VLMO_SIDE_STREAM', 'low')
 PROBE_STREAMS = _os.environ.get('VLMO_PROBE_STREAMS', '1') != '0'
 MERGE_SEPARATE_ATTENTION = _os.environ.get('VLMO_MERGE_ATTN', '1') != '0'
@@ -482,7 +500,7 @@ class BlockFn(torch.autograd.Function):
         ncols = max(3 * d, hid, 2 * d * (3 + len(meta.expert_ranges)))
         ws_main = hip.workspace(dev, ncols)
         D.ws_main, D.ws_bytes = ws_main.data_ptr(), ws_main.numel() * 4
-        side = _side_stream(dev) if OVERLAP_WGRAD else None
+        side = _side_stream(dev) if _use_side_stream(sink, M) else None
         tn_need = hip.lib().vlmo_gemm_tn_ws_bytes(M, hid, d)
         if side is not None:
             with torch.cuda.stream(side):
@@ -822,7 +840,7 @@ class StackFn(torch.autograd.Function):
         S = hip.StackDesc()
         S.n_blocks, S.wgrad_batch, S.n_tmp_sets, S.wgrad_store = nb, batch, nsets, int(store_ok)
         S.blocks = ctypes.cast(descs, ctypes.POINTER(hip.BlockDesc))
-        side = _side_stream(dev) if OVERLAP_WGRAD else None
+        side = _side_stream(dev) if _use_side_stream(sink, M) else None
         S.side_stream = side.cuda_stream if side is not None else None
         evs = None
         if sink is not None and side is not None:

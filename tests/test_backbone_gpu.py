@@ -280,6 +280,37 @@ def test_native_stack_path_equals_per_block_path(preset, B):
 
 
 @pytest.mark.parametrize('stack', [True, False])
+def test_one_stream_and_side_stream_schedules_give_the_same_gradients(stack):
+    """engine.OVERLAP_WGRAD: weight gradients and column folds on the caller's stream (the default without a gradient
+    reducer) or on the side stream (the default under one, VLMO_OVERLAP_WGRAD=1 always).  Same kernels on the same
+    operands: outputs bit-identical, gradients equal up to the order of the fp32 atomics (column folds, embeddings)."""
+    from exploremultimodal_amd import engine
+    model, mc = build('small', drop=0.1, drop_path=0.1)
+    model.train()
+    B = 5
+    batch = synth.synth_batch(mc, B, seed=79)
+    kw = modes(mc, batch, B)['vl']
+    R = torch.randn(B, mc.max_text_len + synth.num_img_tokens(mc), mc.embed_dim, device=DEV)
+    old = engine.USE_STACK, engine.OVERLAP_WGRAD
+    try:
+        engine.USE_STACK = stack
+        engine.OVERLAP_WGRAD = False
+        x1, g1 = _vl_step(model, kw, R, 3)
+        engine.OVERLAP_WGRAD = True
+        x2, g2 = _vl_step(model, kw, R, 3)
+        engine.OVERLAP_WGRAD = None
+        x3, g3 = _vl_step(model, kw, R, 3)          # auto: no reducer here -> one stream
+    finally:
+        engine.USE_STACK, engine.OVERLAP_WGRAD = old
+    assert torch.equal(x1, x2) and torch.equal(x1, x3)
+    assert set(g1) == set(g2) == set(g3)
+    for n in g1:
+        tol = 1e-3 * g1[n].abs().max().item() + 1e-9        # the bound two runs of ONE schedule are held to above
+        assert (g1[n] - g2[n]).abs().max().item() <= tol, (n, (g1[n] - g2[n]).abs().max().item(), tol)
+        assert (g1[n] - g3[n]).abs().max().item() <= tol, (n, (g1[n] - g3[n]).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize('stack', [True, False])
 def test_split_backward_attention_regenerates_the_forward_dropout_mask(stack):
     """Below the fusion layer text and image sequences share ONE forward attention launch and the backward runs as two
     right-sized launches (engine._split_backward_attention).  With attention dropout on (vlmo.py:93; 0.1 in every
