@@ -161,6 +161,32 @@ def test_encoder_full_ids_vs_reference(golden_dir):
     assert np.abs(lm - g['logits_max']).max() <= 3e-2
 
 
+def test_output_convolution_row_split_equals_one_launch():
+    """Encoder._row_parts: at 12 images of 112 x 112 the output convolution has 10 x 32 = 320 tiles of 256 x 256 = one
+    full dispatch round + a quarter; the rows of the partial round go out as 128 x 128 tiles (a second launch).  Logits
+    (fp32 epilogue) and ids (fused arg-max epilogue) against the one-launch form: the same products in another
+    summation order."""
+    from exploremultimodal_amd import dvae
+    enc = _encoder()
+    assert enc._row_parts(12 * 196, 8192) == [(0, 2048, 3), (2048, 2352, 0)]
+    assert enc._row_parts(2 * 196, 8192) == [(0, 392, -1)] and enc._row_parts(64 * 196, 8192)[1] == (12288, 12544, 0)
+    gen = torch.Generator().manual_seed(5)
+    x = (0.8 * torch.rand(12, 3, 112, 112, generator=gen) + 0.1).to(DEV)
+    old = dvae.OUTPUT_ROW_SPLIT
+    try:
+        dvae.OUTPUT_ROW_SPLIT = True
+        lo_s, ids_s = enc(x).float(), enc.codebook_indices(x)
+        dvae.OUTPUT_ROW_SPLIT = False
+        assert enc._row_parts(12 * 196, 8192) == [(0, 2352, -1)]
+        lo_1, ids_1 = enc(x).float(), enc.codebook_indices(x)
+    finally:
+        dvae.OUTPUT_ROW_SPLIT = old
+    assert (lo_s - lo_1).abs().max().item() <= 1e-4
+    assert torch.equal(lo_s[:10], lo_1[:10])        # images 0..9 = matrix rows below 1 960: the same tiles in both forms
+    assert (ids_s == ids_1).float().mean().item() >= 0.999
+    assert torch.equal(ids_s, lo_s.argmax(1)) or (ids_s == lo_s.argmax(1)).float().mean().item() >= 0.999
+
+
 def test_encoder_input_checks():
     from exploremultimodal_amd.dvae import Encoder, create_d_vae
     enc = Encoder(n_hid=256, vocab_size=512).to(DEV)
