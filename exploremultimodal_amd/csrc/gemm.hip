@@ -1969,12 +1969,20 @@ int run_nt(int epi, int dtype, int tile, GemmNTGroups& gp, hipStream_t stream) {
     return launch_nt<bf16, 128, 128, 2, 2>(epi, gp, stream);
 }
 
-int group_m_default() {
-    static const int v = [] {
+// Row-tiles per group of the L2 tile order.  VLMO_GROUP_M fixes it (measurement aid).  Else by the bytes of the weight
+// matrix: a group is group_m row panels against ALL column tiles, so group_m = 1 streams the whole weight once per row
+// panel -- cheap while the weight is of the size of an XCD's L2 (4 MB), and then the activation panel is fetched once;
+// larger weights want their column tiles reused across several row panels.  In-step sweeps (tools/ab_multi.sh, weight
+// gradients on the main stream): VLMo-Base (weights <= 4.7 MB) group_m 1 / 2 / 3 / 4 = 14.34 / 14.36 / 14.38 / 14.43 ms;
+// VLMo-Large (2 - 8.4 MB) 24.88 against 24.79 at 4; the dVAE encoder (output convolution: 67 MB) 6.03 against 5.92 ms at 4.
+// (Under the side stream round 3 had measured 2 - 6 equal, 8 +0.1 ms, 16 +0.35 ms.)
+int group_m_for(int N, int K) {
+    static const int forced = [] {
         const char* sv = getenv("VLMO_GROUP_M");
-        return sv ? atoi(sv) : 4;       // in-step sweep (bench.py, one box): 2-6 within noise of each other, 8 +0.1 ms, 16 +0.35 ms
+        return sv ? atoi(sv) : 0;
     }();
-    return v;
+    if (forced > 0) return forced;
+    return (long)N * K * 2 <= 5l << 20 ? 1 : 4;
 }
 }  // namespace
 
@@ -1983,7 +1991,7 @@ extern "C" int vlmo_gemm_nt(int epi, int dtype, int tile, const void* A, int lda
     if (int rc = check_nt(epi, A, lda, B, ldb, M, N, K, e)) return rc;
     GemmNTGroups gp{};
     gp.ngroups = 1;
-    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_default(), nullptr, 0, 0, 1.f};
+    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_for(N, K), nullptr, 0, 0, 1.f};
     return run_nt(epi, dtype, tile, gp, stream);
 }
 
@@ -1996,7 +2004,7 @@ extern "C" int vlmo_gemm_nt_2src(int epi, int dtype, int tile, const void* A, in
     if (int rc = check_nt(epi, A, K > lda ? K : lda, B, ldb, M, N, K, e)) return rc;
     GemmNTGroups gp{};
     gp.ngroups = 1;
-    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_default(), A2, lda2, k1, seg_scale};
+    gp.g[0] = GemmNT{A, B, M, N, K, lda, ldb, *e, 0, 0, 0, 0, nullptr, group_m_for(N, K), A2, lda2, k1, seg_scale};
     return run_nt(epi, dtype, tile, gp, stream);
 }
 
@@ -2014,7 +2022,7 @@ extern "C" int vlmo_gemm_nt_grouped(int epi, int dtype, int tile, int ngroups, c
     gp.ngroups = ngroups;
     for (int q = 0; q < ngroups; ++q) {
         if (int rc = check_nt(epi, A[q], lda, B[q], ldb, M[q], N, K, &e[q])) return rc;
-        gp.g[q] = GemmNT{A[q], B[q], M[q], N, K, lda, ldb, e[q], 0, 0, 0, 0, nullptr, group_m_default(), nullptr, 0, 0, 1.f};
+        gp.g[q] = GemmNT{A[q], B[q], M[q], N, K, lda, ldb, e[q], 0, 0, 0, 0, nullptr, group_m_for(N, K), nullptr, 0, 0, 1.f};
     }
     return run_nt(epi, dtype, tile, gp, stream);
 }
